@@ -1,0 +1,169 @@
+"""Pins the CPU oracle (oracle/bfp_oracle.c) against outputs of the reference itself
+(tests/golden/*.npz, made by tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from util import DT, load, from_bits, bits, assert_bits_equal
+from gen import int_bits_tensor
+from oracle import oracle as O
+
+
+def cfg(**kw):
+    base = dict(mant_bits=3, epsilon=1e-8, rounding_mode='determ', device='cpu', block_size=64,
+                num_format='bfp', weight_mant_bits=15, in_sparsity=False, w_sparsity=False,
+                grad_sparsity=False, sparsity_frac=0.5, N=2, M=4, sparsity_num_format='bfp',
+                first='s', sparsity_mode='structured')
+    base.update(kw)
+    return base
+
+
+def test_g1_exponents_16bit():
+    g = load("g1_exponent.npz")
+    for name, hi in (("bf16", 0x7F80), ("f16", 0x7C00)):
+        pat = np.arange(0, hi, dtype=np.uint16)
+        x = from_bits(pat, DT[name]).view(-1, 1)
+        _, e = O.no_sparsity_float_to_bfp(x, 1, 3, 1e-8, return_exponents=True)
+        want = g[f"{name}_e"]
+        got = e.view(-1).numpy()
+        assert np.array_equal(got, want), (name, np.flatnonzero(got != want)[:10])
+
+
+def test_g1_exponents_f32_and_eps():
+    g = load("g1_exponent.npz")
+    x = from_bits(g["f32_bits"], torch.float32).view(-1, 1)
+    _, e = O.no_sparsity_float_to_bfp(x, 1, 3, 1e-8, return_exponents=True)
+    assert np.array_equal(e.view(-1).numpy(), g["f32_e"])
+    for eps_name, eps in (("1e-6", 1e-6), ("0", 0.0)):
+        x = from_bits(g[f"bf16_eps{eps_name}_bits"], torch.bfloat16).view(-1, 1)
+        _, e = O.no_sparsity_float_to_bfp(x, 1, 3, eps, return_exponents=True)
+        assert np.array_equal(e.view(-1).numpy(), g[f"bf16_eps{eps_name}_e"]), eps_name
+
+
+def test_g1_pow2_is_exact_in_reference():
+    """the reference's torch.pow(2.0, e) is the exact power of two (what the oracle's pow() assumes)"""
+    g = load("g1_exponent.npz")
+    e = g["pow2_e"]
+    want = from_bits(g["pow2_f32"], torch.float32).double().numpy()
+    assert np.array_equal(want, np.ldexp(1.0, e.astype(np.int64)).astype(np.float32).astype(np.float64))
+    wb = from_bits(g["pow2_bf16"], torch.bfloat16).double().numpy()
+    assert np.array_equal(wb, torch.tensor(np.ldexp(1.0, e.astype(np.int64))).to(torch.bfloat16).double().numpy())
+
+
+def test_g2_quantize():
+    g = load("g2_quantize.npz")
+    for sname in ("s0.02", "s1", "s30"):
+        for dname, dt in DT.items():
+            x = from_bits(g[f"in_{sname}_{dname}"], dt)
+            for blk in (16, 32, 64):
+                for m in (3, 5, 7, 15):
+                    y = O.no_sparsity_float_to_bfp(x, blk, m, 1e-8)
+                    assert_bits_equal(bits(y), g[f"out_{sname}_{dname}_b{blk}_m{m}"], dt, f"{sname} {dname} b{blk} m{m}")
+
+
+def test_g3_nm_exhaustive_m4():
+    g = load("g3_nm.npz")
+    rows = torch.from_numpy(g["m4_rows"].astype(np.float32) + 1.0)
+    for N in (1, 2, 3):
+        y = O.structured_N_M_sparsity(rows, N, 4)
+        assert np.array_equal((y != 0).numpy().astype(np.uint8), g[f"m4_keep_N{N}"]), N
+
+
+@pytest.mark.parametrize("NM", [(2, 8), (4, 8), (1, 8), (7, 8), (4, 16), (8, 16), (2, 16), (16, 32), (8, 32), (1, 2), (3, 6), (2, 5)])
+def test_g3_nm_tie_heavy(NM):
+    N, M = NM
+    g = load("g3_nm.npz")
+    r = g[f"rows_{N}_{M}"].astype(np.float32) + 1.0
+    sign = np.where(g[f"sign_{N}_{M}"] != 0, -1.0, 1.0).astype(np.float32)
+    y = O.structured_N_M_sparsity(torch.from_numpy(r * sign), N, M)
+    keep = np.packbits((y != 0).numpy().astype(np.uint8), axis=1)
+    assert np.array_equal(keep, g[f"keep_{N}_{M}"])
+
+
+@pytest.mark.parametrize("M", [16, 32, 64])
+def test_g3_nm_killer(M):
+    g = load("g3_nm.npz")
+    r = g[f"killer_rows_{M}"].astype(np.float32) + 1.0
+    y = O.structured_N_M_sparsity(torch.from_numpy(r), M // 2, M)
+    assert np.array_equal(np.packbits((y != 0).numpy().astype(np.uint8), axis=1), g[f"killer_keep_{M}"])
+
+
+def test_g3_nm_real():
+    g = load("g3_nm.npz")
+    for dname, dt in DT.items():
+        x = from_bits(g[f"real_in_{dname}"], dt)
+        for (N, M) in ((2, 4), (1, 4), (3, 4), (4, 8), (2, 16)):
+            assert_bits_equal(bits(O.structured_N_M_sparsity(x, N, M)), g[f"real_out_{dname}_{N}_{M}"], dt, f"{dname} {N}:{M}")
+
+
+def test_g4_composed():
+    g = load("g4_composed.npz")
+    for dname, dt in DT.items():
+        x = from_bits(g[f"in_{dname}"], dt)
+        for first in ('s', 'q'):
+            for mode, extra in (("structured", dict(N=2, M=4)), ("structured", dict(N=1, M=4)),
+                                ("structured", dict(N=4, M=8)), ("unstructured", dict(sparsity_frac=0.5)),
+                                ("unstructured", dict(sparsity_frac=0.3))):
+                for m, blk in ((3, 64), (7, 32), (7, 16)):
+                    c = cfg(mant_bits=m, block_size=blk, first=first, sparsity_mode=mode, w_sparsity=True, **extra)
+                    y = O.float_to_bfp_blocked(x, **c, identifier='w')
+                    tag = f"{dname}_{first}_{mode[:1]}_{extra.get('N', 0)}_{extra.get('M', 0)}_{extra.get('sparsity_frac', 0)}_m{m}_b{blk}"
+                    assert_bits_equal(bits(y), g[f"out_{tag}"], dt, tag)
+        for ident in ('w', 'in', 'grad', ''):
+            for flag in ('in_sparsity', 'w_sparsity', 'grad_sparsity'):
+                y = O.float_to_bfp_blocked(x, **cfg(**{flag: True}), identifier=ident)
+                assert_bits_equal(bits(y), g[f"ident_{dname}_{ident or 'none'}_{flag}"], dt, f"ident {ident} {flag}")
+        y = O.float_to_bfp_blocked(x, **cfg(sparsity_num_format='fp32', w_sparsity=True), identifier='w')
+        assert_bits_equal(bits(y), g[f"fp32fmt_{dname}"], dt, "fp32fmt")
+        y = O.float_to_bfp_blocked(x, **cfg(weight_mant_bits=15), identifier='', sgd_update=True)
+        assert_bits_equal(bits(y), g[f"sgd_{dname}"], dt, "sgd")
+
+
+def test_g5_unstructured_small_and_big():
+    g = load("g5_unstructured.npz")
+    x = from_bits(g["small_in"], torch.bfloat16)
+    for frac in (0.5, 0.25, 0.9, 0.001):
+        assert_bits_equal(bits(O.unstructured_sparsity(x, frac)), g[f"small_out_{frac}"], torch.bfloat16, f"frac {frac}")
+    # tie positions too: the oracle restates the same sequential introselect
+    for dname, shape, seed in (("bf16", (512, 1024), 11), ("f16", (256, 512), 12), ("f32", (256, 512), 13)):
+        x = from_bits(int_bits_tensor(shape, dname, seed), DT[dname]).view(shape)
+        y = O.unstructured_sparsity(x, 0.5)
+        z = np.packbits((y == 0).numpy().reshape(-1).astype(np.uint8))
+        assert np.array_equal(z, g[f"big_zero_{dname}"]), dname
+
+
+def test_g6_padding():
+    g = load("g6_padding.npz")
+    for C in (100, 6, 65, 1, 63, 129):
+        for dname, dt in DT.items():
+            x = from_bits(g[f"in_{C}_{dname}"], dt).view(5, C)
+            assert_bits_equal(bits(O.no_sparsity_float_to_bfp(x, 64, 3)), g[f"q_{C}_{dname}"], dt, f"q {C} {dname}")
+            assert_bits_equal(bits(O.structured_N_M_sparsity(x, 2, 4)), g[f"nm_{C}_{dname}"], dt, f"nm {C} {dname}")
+            for first in ('s', 'q'):
+                y = O.float_to_bfp_blocked(x, **cfg(first=first, w_sparsity=True), identifier='w')
+                assert_bits_equal(bits(y), g[f"comp_{first}_{C}_{dname}"], dt, f"comp {first} {C} {dname}")
+                y = O.float_to_bfp_blocked(x, **cfg(first=first, w_sparsity=True, N=3, M=8, block_size=16, mant_bits=7), identifier='w')
+                assert_bits_equal(bits(y), g[f"comp38_{first}_{C}_{dname}"], dt, f"comp38 {first} {C} {dname}")
+
+
+def test_g7_edges():
+    g = load("g7_edges.npz")
+    for dname, dt in DT.items():
+        x = from_bits(g[f"in_{dname}"], dt).view(-1, 16)
+        for m in (3, 7, 15):
+            y = O.no_sparsity_float_to_bfp(x, 16, m)
+            assert_bits_equal(bits(y), g[f"out_{dname}_m{m}"], dt, f"edges {dname} m{m}")
+        assert_bits_equal(bits(O.structured_N_M_sparsity(x, 2, 4)), g[f"nm_{dname}"], dt, f"edges nm {dname}")
+
+
+def test_g8_nd():
+    g = load("g8_nd_linear.npz")
+    c = cfg(mant_bits=7, block_size=16, N=1, M=4, in_sparsity=True, w_sparsity=True)
+    for dname, dt in DT.items():
+        a = from_bits(g[f"act_in_{dname}"], dt).view(2, 7, 128)
+        assert_bits_equal(bits(O.float_to_bfp_blocked(a, **c, identifier='in')), g[f"act_out_{dname}"], dt, "act")
+        w = from_bits(g[f"conv_in_{dname}"], dt).view(8, 3, 16, 16)
+        assert_bits_equal(bits(O.float_to_bfp_blocked(w, **c, identifier='w')), g[f"conv_out_{dname}"], dt, "conv")
+        b = from_bits(g[f"mm_b_in_{dname}"], dt).view(2, 4, 32, 16)
+        bq = O.float_to_bfp_blocked(b.transpose(-1, -2).contiguous(), **c, identifier='w').view(2, 4, 16, 32).transpose(-1, -2).contiguous()
+        assert_bits_equal(bits(bq), g[f"mm_b_out_{dname}"], dt, "matmul transpose operand")
