@@ -1,0 +1,145 @@
+/*
+ * bfpq.h -- C ABI of libbfpq.so, the MI355X (gfx950) BFP quantize + sparsify engine.
+ *
+ * This is the drop-in boundary for the reference's hot path
+ *     src/transformers/bfp/bfp_ops.py:16-149   (get_exponent, _convert_blocked_float_to_bfp,
+ *     _no_sparsity_float_to_bfp, _structured_N_M_sparsity, _unstructured_sparsity, _sparsify,
+ *     _quantize, float_to_bfp_blocked)
+ * The reference has no native code on this path (it is ~25 ATen passes per call); these entry
+ * points are what a ctypes / pybind binding placed in that file would call instead.
+ *
+ * Conventions
+ *   - every pointer named *_dev is a DEVICE pointer owned by the caller; *_host is host memory
+ *   - tensors are dense row-major [rows, cols]; blocks and N:M groups run along cols only and
+ *     never cross a row (bfp_ops.py:50-59, :79-91); leading dims are flattened into rows
+ *   - dtype: BFPQ_F32 / BFPQ_F16 / BFPQ_BF16 (input and dequantised output share the dtype)
+ *   - launches are asynchronous on `stream` (a hipStream_t passed as void*); nothing here
+ *     synchronises, allocates or frees device memory, so every call is hipGraph-capturable
+ *   - return value: 0 on success, a negative BFPQ_E_* for argument errors, a positive
+ *     hipError_t if a launch failed
+ *   - rounding is round-half-to-even ('determ', bfp_ops.py:24-25) unless a stochastic seed is given
+ */
+#ifndef BFPQ_H
+#define BFPQ_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BFPQ_VERSION 1
+
+enum { BFPQ_F32 = 0, BFPQ_F16 = 1, BFPQ_BF16 = 2 };
+
+enum {
+    BFPQ_E_ARG = -1,        /* bad shape / pointer / enum                                        */
+    BFPQ_E_UNSUPPORTED = -2,/* valid in the reference but not handled by this entry point        */
+    BFPQ_E_ALIGN = -3       /* a fast-path entry point was given a misaligned pointer            */
+};
+
+/* sizes of the small constant tables the kernels read (built on the host, uploaded by the caller
+ * once per device; keeping them caller-owned keeps the library stateless) */
+#define BFPQ_EXP_WIN_ENTRIES 320   /* uint8 per unbiased exponent k in [-160, 160)              */
+#define BFPQ_NM4_LUT_ENTRIES 729   /* uint8 keep-mask per 3^6 pairwise-comparison signature     */
+
+int bfpq_version(void);
+const char* bfpq_error_string(int code);
+
+/* ---- host-side table builders ---------------------------------------------------------------
+ * bfpq_exp_window_host: replaces the dtype-dependent rounding inside get_exponent
+ * (bfp_ops.py:29-33): for s = 2^k (1+f) the reference's ceil(log2(s)) evaluated in `dtype` is k
+ * when the dtype mantissa field of s is <= table[k + 160], else k + 1.
+ * bfpq_nm4_lut_host: keep-mask (bit i set = element i kept) of one group of 4 for "keep N of 4",
+ * indexed by sum_{p} c_p 3^p over pairs p = (0,1),(0,2),(0,3),(1,2),(1,3),(2,3) with
+ * c = 0/1/2 for |a_i| <,==,> |a_j|; reproduces ATen CPU topk's std::nth_element tie order
+ * used by _structured_N_M_sparsity (bfp_ops.py:85). */
+int bfpq_exp_window_host(int dtype, uint8_t* table_host /* [BFPQ_EXP_WIN_ENTRIES] */);
+int bfpq_nm4_lut_host(int N, uint8_t* lut_host /* [BFPQ_NM4_LUT_ENTRIES] */);
+/* host restatement of the N:M selection for one group (any 1 <= N <= M <= 64); keys are
+ * non-negative magnitudes compared as unsigned integers. Returns the 64-bit PRUNE mask. Used by the
+ * host-logic tests and to build the LUT above. */
+uint64_t bfpq_nm_prune_mask_host(const uint32_t* keys, int N, int M);
+
+/* ---- fused quantize (+ N:M) -----------------------------------------------------------------
+ * Replaces float_to_bfp_blocked (bfp_ops.py:124-149) for sparsity_mode 'structured' or no
+ * sparsity, sparsity_num_format 'bfp' or 'fp32':
+ *     sparsify_first != 0:  out = Q(S(in))   (first == 's')
+ *     sparsify_first == 0:  out = S(Q(in))
+ * with Q = _no_sparsity_float_to_bfp (block_size, mant_bits; block_size == 0 -> identity, the
+ * 'fp32' format) and S = _structured_N_M_sparsity (N, M; M == 0 -> identity).
+ * Outputs (each nullable, at least one required):
+ *   out_deq_dev   [rows, cols] dtype          the reference's fake-quantised tensor (drop-in mode)
+ *   out_codes_dev sign-magnitude mantissas as two's-complement integers, code_bits wide
+ *                 (4: two per byte, low nibble first, [rows, ceil(cols/2)] bytes; 8: int8; 16: int16)
+ *   out_exp_dev   int8 [rows, ceil(cols/block)] shared exponent e (value = code * 2^(e-mant_bits));
+ *                 saturated to [-127, 127]; -128 marks a block the reference turns into NaN
+ * Any shape, block size and 1 <= N <= M <= 64 is accepted; the single-pass fused kernel is used
+ * when cols % block == 0, block is 16 bytes x a power of two <= 64 lanes, and M in {0, 2, 4}
+ * divides the block; otherwise the work is split into a sparsify and a quantize launch through
+ * scratch_dev (rows*cols elements of dtype, may be NULL when the fused kernel applies).
+ * stoch_seed == 0 -> round-half-even; otherwise stochastic rounding (uniform dither in
+ * [-0.5, 0.5) from a counter-based generator keyed by (seed, element index), bfp_ops.py:21-23). */
+int bfpq_quantize_nm(const void* in_dev, void* out_deq_dev, void* out_codes_dev, int8_t* out_exp_dev,
+                     int64_t rows, int64_t cols, int dtype,
+                     int block_size, int mant_bits, double epsilon,
+                     int N, int M, int sparsify_first,
+                     int code_bits, uint64_t stoch_seed,
+                     const uint8_t* exp_win_dev, const uint8_t* nm4_lut_dev,
+                     void* scratch_dev, void* stream);
+
+/* returns 1 if bfpq_quantize_nm would take the single-pass fused kernel for this problem */
+int bfpq_is_fused(int64_t rows, int64_t cols, int dtype, int block_size, int N, int M);
+
+/* ---- N:M only (replaces _structured_N_M_sparsity, bfp_ops.py:73-91) --------------------------- */
+int bfpq_nm_sparsify(const void* in_dev, void* out_dev, int64_t rows, int64_t cols, int dtype,
+                     int N, int M, const uint8_t* nm4_lut_dev, void* stream);
+
+/* ---- unstructured magnitude pruning (replaces _unstructured_sparsity, bfp_ops.py:61-71) -------
+ * Exact global k-th smallest |v| by radix select on the magnitude bit pattern, in steps so that a
+ * multi-GPU caller can all-reduce between them (row-sharded tensors share one threshold):
+ *   1. for pass p in [0, bfpq_select_passes(dtype)):
+ *        bfpq_select_hist(...)      per-device histogram of the current digit  -> hist_dev
+ *        [all-reduce hist_dev across ranks]
+ *        bfpq_select_scan(...)      picks the digit, updates state_dev
+ *   2. bfpq_tie_count(...)          elements equal to the threshold per chunk  -> tie_counts_dev
+ *        [multi-GPU: exchange per-rank totals, pass the sum of lower ranks as tie_base]
+ *   3. bfpq_threshold_apply(...)    zeroes every |v| < tau and the first `need` (in flat index
+ *                                   order, lower ranks first) of the |v| == tau
+ * state_dev: BFPQ_SELECT_STATE_BYTES bytes, hist_dev: BFPQ_SELECT_HIST_BINS uint32 (the caller
+ * zeroes hist_dev before every bfpq_select_hist), tie_counts_dev: BFPQ_TIE_CHUNKS uint32.
+ * k is the global prune count int(numel_global * frac) (bfp_ops.py:66).
+ * Tie positions: the reference's are those of a sequential introselect over the whole tensor and
+ * are not reproduced; threshold, count and every element outside the tie class are. */
+#define BFPQ_SELECT_STATE_BYTES 64
+#define BFPQ_SELECT_HIST_BINS 32768
+#define BFPQ_TIE_CHUNKS 2048
+
+int bfpq_select_passes(int dtype);
+int bfpq_select_init(void* state_dev, int64_t k, void* stream);
+int bfpq_select_hist(const void* in_dev, int64_t numel, int dtype, int pass,
+                     const void* state_dev, uint32_t* hist_dev, void* stream);
+int bfpq_select_scan(int dtype, int pass, void* state_dev, const uint32_t* hist_dev, void* stream);
+int bfpq_tie_count(const void* in_dev, int64_t numel, int dtype, const void* state_dev,
+                   uint32_t* tie_counts_dev, void* stream);
+int bfpq_threshold_apply(const void* in_dev, void* out_dev, int64_t numel, int dtype,
+                         const void* state_dev, const uint32_t* tie_counts_dev,
+                         const int64_t* tie_base_dev /* nullable: 0 */, void* stream);
+
+/* layout of state_dev as read back by a host that wants tau / counts (all little-endian) */
+typedef struct bfpq_select_state {
+    uint32_t prefix;      /* magnitude bits decided so far (high digits)                         */
+    uint32_t prefix_mask; /* which bits of prefix are decided                                    */
+    int64_t k_rem;        /* how many of the elements matching prefix are still to be pruned     */
+    uint32_t tau;         /* after the last pass: magnitude bit pattern of the threshold         */
+    uint32_t done;        /* 1 after the last pass                                               */
+    int64_t need;         /* how many elements equal to tau get pruned                           */
+    int64_t ties;         /* how many elements equal tau in total                                */
+    int64_t k;            /* the k given to bfpq_select_init                                     */
+    int64_t reserved[2];
+} bfpq_select_state;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BFPQ_H */

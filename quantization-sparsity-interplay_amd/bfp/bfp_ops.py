@@ -1,0 +1,320 @@
+"""Drop-in operator surface of the reference's src/transformers/bfp/bfp_ops.py, backed by the
+MI355X HIP engine (libbfpq.so).  Same names, argument order, aliasing and exceptions as the
+reference (file:line cited per function); the tensor math itself is NOT here -- it is in
+csrc/bfpq_kernels.hip, reached through ..native.  ROCm-device tensors only: a CPU tensor raises
+NativeUnavailable (there is deliberately no CPU fallback).
+
+Differences from the reference, all documented in DESIGN.md:
+  * 'stoc' rounding draws its dither from a counter-based generator seeded from torch's CPU RNG
+    (torch.manual_seed controls it); the reference's torch.rand stream is not reproduced.
+  * _unstructured_sparsity: which of the elements EQUAL to the threshold are pruned is "lowest flat
+    index first"; the reference's choice is an artefact of a sequential introselect.
+  * sparsity_num_format == 'int' (SparseGPT per-channel quantizer, bfp_ops.py:111-120) is not built.
+"""
+import torch
+import torch.nn.functional as F
+
+from .. import native
+
+__all__ = ["rounding_modes", "round_tensor", "get_exponent", "float_to_bfp_blocked", "float_to_bfp_packed",
+           "sparsify", "unpack_bfp_args", "F_linear_bfp", "F_matmul_bfp", "BFPLinear", "BFPConv2d"]
+
+
+class rounding_modes:
+    """reference: bfp_ops.py:16-18"""
+    STOC, DETERM = 'stoc', 'determ'
+    modes = [STOC, DETERM]
+
+
+def _seed_for(mode):
+    """0 -> round-half-even; otherwise a non-zero 62-bit seed taken from torch's CPU generator"""
+    if mode == rounding_modes.DETERM:
+        return 0
+    if mode == rounding_modes.STOC:
+        return int(torch.randint(1, 2 ** 62, (1,)).item())
+    raise NotImplementedError("Rounding mode %s is not implemented", mode)
+
+
+def _stoc_dtype(t, mode):
+    """reference quirk: 'stoc' adds fp32 noise, so a half input comes back as fp32"""
+    return t.float() if (mode == rounding_modes.STOC and t.dtype != torch.float32) else t
+
+
+def round_tensor(t, mode, device):
+    """reference: bfp_ops.py:20-27 (elementwise; kept for API completeness, not on the fused path)"""
+    if mode == rounding_modes.STOC:
+        sampled = torch.rand(t.shape, device=t.device) - 0.5
+        return sampled.add_(t).round()
+    elif mode == rounding_modes.DETERM:
+        return t.round()
+    raise NotImplementedError("Rounding mode %s is not implemented", mode)
+
+
+def get_exponent(t, epsilon):
+    """reference: bfp_ops.py:29-33 -- t is [nblk, block]; returns the shared exponent per row, [nblk, 1],
+    in t.dtype.  (int8 transport: exponents outside [-127, 127] saturate; NaN blocks come back as NaN.)"""
+    native.require_device_tensor(t)
+    assert t.dim() == 2
+    _, _, e = native.quantize_nm(t, t.shape[1], 0, epsilon, want_deq=False, want_exp=True)
+    out = e.to(t.dtype).view(-1, 1)
+    return torch.where(e.view(-1, 1) == -128, torch.full_like(out, float('nan')), out)
+
+
+def _convert_blocked_float_to_bfp(t, mant_bits, epsilon, rounding_mode, device):
+    """reference: bfp_ops.py:35-44 -- every row of the 2-D t is one block"""
+    native.require_device_tensor(t)
+    assert t.dim() == 2
+    y, _, _ = native.quantize_nm(t, t.shape[1], mant_bits, epsilon, stoch_seed=_seed_for(rounding_mode))
+    return _stoc_dtype(y, rounding_mode)
+
+
+def _no_sparsity_float_to_bfp(t, block_size, mant_bits, epsilon, rounding_mode, device):
+    """reference: bfp_ops.py:46-59 -- blocks of block_size along the last dim, zero-padded per row"""
+    native.require_device_tensor(t)
+    y, _, _ = native.quantize_nm(t, block_size, mant_bits, epsilon, stoch_seed=_seed_for(rounding_mode))
+    return _stoc_dtype(y.view(t.shape), rounding_mode)
+
+
+_select_ws = {}
+
+
+def _workspace(device):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _select_ws.get(key)
+    if ws is None:
+        ws = _select_ws[key] = native.SelectWorkspace(device)
+    return ws
+
+
+def _unstructured_sparsity(t, device, sparsity_frac=0):
+    """reference: bfp_ops.py:61-71 -- zero the int(numel*frac) smallest |v| of the whole tensor"""
+    assert (sparsity_frac > 0)
+    native.require_device_tensor(t)
+    k = int(t.numel() * sparsity_frac)
+    if k > t.numel():
+        raise RuntimeError("selected index k out of range")      # what torch.topk raises in the reference
+    ws = _workspace(t.device)
+    native.select_threshold(t, k, ws)
+    return native.threshold_apply(t, ws).view(t.shape)
+
+
+def _structured_N_M_sparsity(t, device, N=0, M=0):
+    """reference: bfp_ops.py:73-91 -- per group of M along the last dim keep the N largest |v|"""
+    assert ((N > 0) and (M > 0) and (N <= M))
+    native.require_device_tensor(t)
+    if N == M:
+        return t.contiguous().clone().view(t.shape)
+    y, _, _ = native.quantize_nm(t, 0, 0, 0.0, N=N, M=M)
+    return y.view(t.shape)
+
+
+def _sparsify(t, sparsity, sparsity_mode, device, N, M, sparsity_frac):
+    """reference: bfp_ops.py:93-102"""
+    if sparsity == True:  # noqa: E712  (the reference compares with ==; 1 counts as True)
+        if sparsity_mode == 'structured':
+            return _structured_N_M_sparsity(t, device, N, M)
+        elif sparsity_mode == 'unstructured':
+            return _unstructured_sparsity(t, device, sparsity_frac)
+        else:
+            raise ValueError(f'Unknown sparsity mode: {sparsity_mode} given as argument')
+    else:
+        return t
+
+
+def _quantize(t, num_format, block_size, mant_bits, weight_mant_bits, sgd_update, epsilon, rounding_mode, device, identifier):
+    """reference: bfp_ops.py:104-122"""
+    if num_format == 'fp32':
+        return t
+    elif num_format == 'bfp':
+        if sgd_update:
+            mant_bits = weight_mant_bits
+        return _no_sparsity_float_to_bfp(t, block_size, mant_bits, epsilon, rounding_mode, device)
+    elif num_format == 'int':
+        raise NotImplementedError("sparsity_num_format 'int' (SparseGPT per-channel quantizer, reference "
+                                  "bfp_ops.py:111-120 / int_ops.py) is not built in this engine yet")
+    else:
+        raise ValueError(f'Unknown quantization format: {num_format} given as argument')
+
+
+def _select_sparsity(in_sparsity, w_sparsity, grad_sparsity, identifier):
+    """reference: bfp_ops.py:132-139"""
+    if in_sparsity == True and identifier == 'in':  # noqa: E712
+        return True
+    elif w_sparsity == True and identifier == 'w':  # noqa: E712
+        return True
+    elif grad_sparsity == True and identifier == 'grad':  # noqa: E712
+        return True
+    return False
+
+
+def float_to_bfp_blocked(t, mant_bits, epsilon, rounding_mode, device, block_size,
+                         num_format, weight_mant_bits, in_sparsity, w_sparsity, grad_sparsity,
+                         sparsity_frac, N, M, sparsity_num_format, first, sparsity_mode, identifier='', sgd_update=False,
+                         mx_w_elem_format='', mx_a_elem_format='', scale_bits=0, bfloat=0):
+    """reference: bfp_ops.py:124-149.  Structured sparsity + 'bfp' (or 'fp32') runs as ONE fused
+    kernel launch in either order; everything else composes the same steps the reference does."""
+    assert (num_format == 'bfp')
+    assert (((sparsity_num_format == 'bfp') and (block_size > 0)) or (sparsity_num_format == 'fp32') or (sparsity_num_format == 'int'))
+
+    sparsity = _select_sparsity(in_sparsity, w_sparsity, grad_sparsity, identifier)
+
+    if sparsity and sparsity_mode == 'structured' and sparsity_num_format == 'bfp':
+        assert ((N > 0) and (M > 0) and (N <= M))
+        native.require_device_tensor(t)
+        mb = weight_mant_bits if sgd_update else mant_bits
+        y, _, _ = native.quantize_nm(t, block_size, mb, epsilon, N=N if N < M else 0, M=M if N < M else 0,
+                                     sparsify_first=(first == 's'), stoch_seed=_seed_for(rounding_mode))
+        return _stoc_dtype(y.view(t.shape), rounding_mode)
+
+    if first == 's':
+        sparse_t = _sparsify(t, sparsity, sparsity_mode, device, N, M, sparsity_frac)
+        return _quantize(sparse_t, sparsity_num_format, block_size, mant_bits, weight_mant_bits, sgd_update, epsilon, rounding_mode, device, identifier)
+    else:
+        quant_t = _quantize(t, sparsity_num_format, block_size, mant_bits, weight_mant_bits, sgd_update, epsilon, rounding_mode, device, identifier)
+        return _sparsify(quant_t, sparsity, sparsity_mode, device, N, M, sparsity_frac)
+
+
+# ---- additive public surface (no counterpart in the reference) -------------------------------
+def sparsify(t, sparsity_mode, N=0, M=0, sparsity_frac=0):
+    """public alias of _sparsify with sparsity=True"""
+    return _sparsify(t, True, sparsity_mode, str(t.device), N, M, sparsity_frac)
+
+
+def float_to_bfp_packed(t, mant_bits, block_size, epsilon=1e-8, N=0, M=0, first='s', code_bits=None, with_dequant=False):
+    """Packed HBFP: integer mantissas (two's complement, 4/8/16 bits; 4-bit = two per byte, low nibble
+    first) + one int8 shared exponent per block, value = code * 2**(exp - mant_bits).  N:M pruning is
+    implied by zero codes.  Returns (codes, exps) or (codes, exps, dequantised)."""
+    native.require_device_tensor(t)
+    if code_bits is None:
+        code_bits = 4 if mant_bits <= 3 else (8 if mant_bits <= 7 else 16)
+    deq, codes, exps = native.quantize_nm(t, block_size, mant_bits, epsilon, N=N, M=M, sparsify_first=(first == 's'),
+                                          want_deq=with_dequant, code_bits=code_bits, want_exp=True)
+    return (codes, exps, deq.view(t.shape)) if with_dequant else (codes, exps)
+
+
+# ---- module / functional wrappers (reference: bfp_ops.py:151-287) -----------------------------
+def MxM_pre_processing(x, w, transpose, **bfp_args):
+    """reference: bfp_ops.py:151-155 -- quantize both GEMM operands; with transpose the second operand is
+    quantized along its contraction dim (blocks must run along K) and handed back in its original layout"""
+    xq = float_to_bfp_blocked(x, **bfp_args, identifier='in')
+    if transpose == True:  # noqa: E712
+        wq = float_to_bfp_blocked(w.transpose(-1, -2), **bfp_args, identifier='w').transpose(-1, -2)
+    else:
+        wq = float_to_bfp_blocked(w, **bfp_args, identifier='w')
+    return xq, wq
+
+
+def _get_op_name(name, epsilon, mant_bits, rounding_mode, **kwargs):
+    """reference: bfp_ops.py:157-158"""
+    return '%s_BFP_%s_%d' % (name, rounding_mode, mant_bits)
+
+
+class _OperandQuantizer(torch.autograd.Function):
+    """forward: (x, w) -> (Q_in(x), Q_w(w)); backward: straight-through (reference NewOpIn, bfp_ops.py:163-170)"""
+
+    @staticmethod
+    def forward(ctx, x, w, transpose, bfp_args):
+        return MxM_pre_processing(x, w, transpose, **bfp_args)
+
+    @staticmethod
+    def backward(ctx, grad_x, grad_w):
+        return grad_x, grad_w, None, None
+
+
+class _GradQuantizer(torch.autograd.Function):
+    """forward: identity; backward: Q_grad(dL/dout) (reference NewOpOut, bfp_ops.py:175-182)"""
+
+    @staticmethod
+    def forward(ctx, out, bfp_args):
+        ctx.bfp_args = bfp_args
+        return out.view_as(out)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return float_to_bfp_blocked(grad_out, **ctx.bfp_args, identifier='grad'), None
+
+
+def _gen_bfp_op(op, name, bfp_args, transpose=False):
+    """reference: bfp_ops.py:160-192 -- wraps `op(x, w, ...)` so that both operands are BFP-quantized
+    (and sparsified) on the way in and the output gradient on the way back."""
+    def bfp_op(x, w, *args, **kwargs):
+        xq, wq = _OperandQuantizer.apply(x, w, transpose, bfp_args)
+        return _GradQuantizer.apply(op(xq, wq, *args, **kwargs), bfp_args)
+
+    bfp_op.__name__ = _get_op_name(name, **bfp_args)
+    return bfp_op
+
+
+def _get_bfp_op(op, name, bfp_args, transpose=False):
+    """reference: bfp_ops.py:194-200 (its cache dict is a local, so there too every layer gets its own op)"""
+    return _gen_bfp_op(op, name, bfp_args, transpose)
+
+
+_BFP_ARG_DEFAULTS = dict(num_format='fp32', sparsity_num_format='fp32', rounding_mode='stoc', epsilon=1e-8,
+                         mant_bits=0, block_size=0, weight_mant_bits=0, in_sparsity=False, w_sparsity=False,
+                         grad_sparsity=False, N=0, M=0, first='s', sparsity_mode='unstructured', sparsity_frac=0,
+                         mx_w_elem_format='', mx_a_elem_format='', bfloat=16, scale_bits=8, device='cpu')
+
+
+def unpack_bfp_args(kwargs):
+    """reference: bfp_ops.py:202-231 -- moves the 20 known keys out of `kwargs` (which is mutated) into a
+    new dict, filling defaults; unknown keys stay behind in `kwargs`."""
+    return {key: kwargs.pop(key, default) for key, default in _BFP_ARG_DEFAULTS.items()}
+
+
+def F_linear_bfp(**kwargs):
+    """reference: bfp_ops.py:233-238"""
+    bfp_args = unpack_bfp_args(kwargs)
+    return _get_bfp_op(F.linear, 'linear', bfp_args) if bfp_args['num_format'] == 'bfp' else F.linear
+
+
+def F_matmul_bfp(**kwargs):
+    """reference: bfp_ops.py:240-245"""
+    bfp_args = unpack_bfp_args(kwargs)
+    return _get_bfp_op(torch.matmul, 'matmul', bfp_args, True) if bfp_args['num_format'] == 'bfp' else torch.matmul
+
+
+class _BFPModule:
+    """shared by BFPLinear / BFPConv2d: config capture before nn.Module.__init__, format dispatch in forward"""
+
+    def _bfp_setup(self, kwargs, functional, op_name):
+        self.bfp_args = unpack_bfp_args(kwargs)
+        self._functional = functional
+        self._op_name = op_name
+
+    def _bfp_finish(self):
+        self.num_format = self.bfp_args['num_format']
+        return _get_bfp_op(self._functional, self._op_name, self.bfp_args)
+
+    def _bfp_forward(self, bfp_op, *operands):
+        if self.num_format == 'fp32':
+            return self._functional(*operands)
+        if self.num_format == 'bfp':
+            return bfp_op(*operands)
+        raise NotImplementedError('NumFormat not implemented')
+
+
+class BFPConv2d(_BFPModule, torch.nn.Conv2d):
+    """reference: bfp_ops.py:247-268 (no extra parameters or buffers: state_dict == nn.Conv2d's)"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1,
+                 padding=0, dilation=1, groups=1, bias=True, **kwargs):
+        self._bfp_setup(kwargs, F.conv2d, 'Conv2d')
+        torch.nn.Conv2d.__init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+        self.conv_op = self._bfp_finish()
+
+    def forward(self, input):
+        return self._bfp_forward(self.conv_op, input, self.weight, self.bias, self.stride, self.padding,
+                                 self.dilation, self.groups)
+
+
+class BFPLinear(_BFPModule, torch.nn.Linear):
+    """reference: bfp_ops.py:270-287 (no extra parameters or buffers: state_dict == nn.Linear's)"""
+
+    def __init__(self, in_features, out_features, bias=True, **kwargs):
+        self._bfp_setup(kwargs, F.linear, 'linear')
+        torch.nn.Linear.__init__(self, in_features, out_features, bias)
+        self.linear_op = self._bfp_finish()
+
+    def forward(self, input):
+        return self._bfp_forward(self.linear_op, input, self.weight, self.bias)

@@ -1,0 +1,1004 @@
+// bfpq_kernels.hip -- gfx950 kernels + C-ABI launchers of libbfpq.so (see include/bfpq.h).
+//
+// Reference path replaced: src/transformers/bfp/bfp_ops.py:16-149.
+//
+// Kernels
+//   k_fused_flat   the hot kernel: [N:M mask] + shared exponent + mantissa rounding in ONE pass.
+//                  16 B per lane per access, a block of `block_size` elements lives in `lpb`
+//                  adjacent lanes of one wavefront (block 64 bf16 = 8 lanes), block max by
+//                  cross-lane xor-shuffles, N:M keep-mask from a 729-entry LDS table, no atomics,
+//                  no LDS staging of data, no second read.  HBM-bound: 2 x sizeof(dtype) B/elem.
+//   k_nm_rows      general N:M (any M <= 64, ragged rows): one thread per group, the group's
+//                  (key,index) pairs in an LDS column, libstdc++ introselect replayed (nm_select.h)
+//   k_quant_rows   general HBFP quantizer (any block size, ragged rows): a power-of-two lane group
+//                  per block, two sweeps (max, then quantize)
+//   k_select_*     radix select of the k-th smallest magnitude (LDS histogram, then a 1-block scan)
+//   k_tie_count / k_threshold_apply   ordered tie handling + zeroing for unstructured pruning
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include "bfpq.h"
+#include "bfpq_common.h"
+#include "nm_select.h"
+
+using namespace bfpq;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxGrid = 2048;     // 256 CUs x 8 resident workgroups; grid-stride beyond that
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+typedef short short2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t cmp3(uint32_t a, uint32_t b) { return (uint32_t)(a > b) + (uint32_t)(a >= b); }
+
+// signature index of one group of 4 magnitude keys (see bfpq_nm4_lut_host): sum_p c_p 3^p, c in {0,1,2}
+__device__ __forceinline__ uint32_t nm4_index(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3)
+{
+    // keys < 2^31: the signed difference clamped to [-1,1] is the 3-way comparison
+    auto c = [](uint32_t a, uint32_t b) { const int d = (int)a - (int)b; return d < -1 ? -1 : (d > 1 ? 1 : d); };
+    return (uint32_t)(364 + c(k0, k1) + 3 * c(k0, k2) + 9 * c(k0, k3) + 27 * c(k1, k2) + 81 * c(k1, k3) + 243 * c(k2, k3));
+}
+
+// keep-mask of one group of 2 (keep 1): stable insertion sort of two -> index 0 goes on a tie
+__device__ __forceinline__ uint32_t nm2_keep(uint32_t k0, uint32_t k1, int N)
+{
+    if (N >= 2) return 3u;
+    return (k1 < k0) ? 1u : 2u;
+}
+
+// packed 16-bit VALU ops, spelled out: hipcc scalarises a clamp written with vector builtins into
+// per-half v_cmp / v_cndmask chains (seen in the ISA of the first version of this kernel)
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_max_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_mad_i16(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+
+// max over the 2^n adjacent lanes that share one block, by DPP where the ISA has a pattern for it
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_max(uint32_t v)
+{
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ uint32_t shfl_max(uint32_t v, int o)
+{
+    const uint32_t other = (uint32_t)__shfl_xor((int)v, o, 64);
+    return other > v ? other : v;
+}
+// LPBT > 0: lanes per block known at compile time; LPBT < 0: runtime value lpb
+template <int LPBT> __device__ __forceinline__ uint32_t group_max(uint32_t v, int lpb)
+{
+    const int n = LPBT > 0 ? LPBT : lpb;
+    if (n >= 2) v = dpp_max<0xB1>(v);        // quad_perm [1,0,3,2]
+    if (n >= 4) v = dpp_max<0x4E>(v);        // quad_perm [2,3,0,1]
+    if (n >= 8) v = dpp_max<0x141>(v);       // row_half_mirror: the other quad of the 8-lane half
+    if (n >= 16) v = dpp_max<0x140>(v);      // row_mirror: the other half of the 16-lane row
+    if (n >= 32) v = shfl_max(v, 16);
+    if (n >= 64) v = shfl_max(v, 32);
+    return v;
+}
+
+struct FusedArgs {
+    const void* in;
+    void* out_deq;
+    void* out_codes;
+    int8_t* out_exp;
+    int64_t n_items;          // numel / VEC
+    const uint8_t* exp_win;   // global, BFPQ_EXP_WIN_ENTRIES
+    const uint8_t* nm_lut;    // global, BFPQ_NM4_LUT_ENTRIES (NM == 4)
+    uint64_t seed;
+    float eps_dt;
+    int lpb;                  // lanes per block (power of two <= 64); 0 = no quantization
+    int mant_bits;
+    int N;
+    int code_bits;
+    int force_slow;           // mant_bits wider than the dtype significand: always emulate step by step
+};
+
+// scale of a block on the branch-free path; ok == false -> the caller emulates step by step instead
+struct FastScale { float inv, interval, qmax; int e; bool ok; };
+
+template <int DT>
+__device__ __forceinline__ FastScale fast_scale(uint32_t max_key, int mant_bits, float eps_dt, const uint8_t* s_win)
+{
+    using T = Traits<DT>;
+    FastScale f;
+    // max + epsilon rounded to dtype.  bf16: branch-free round-half-even on the bits; a NaN / inf sum
+    // keeps an all-ones exponent (or carries into the sign bit) and fails the range test below
+    uint32_t sb;
+    if constexpr (DT == BFPQ_BF16) {
+        const uint32_t u = f2u(raw_to_f32<DT>(max_key) + eps_dt);
+        sb = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+    } else sb = f2u(rnd<DT>(raw_to_f32<DT>(max_key) + eps_dt));
+    const uint32_t kb = (sb >> 23) & 0x1ffu;                              // biased exponent (9 bits incl. sign: 0 here)
+    const uint32_t mant = (sb >> (23 - T::MBITS)) & ((1u << T::MBITS) - 1u);
+    const uint32_t win = s_win[(kb + 33u) & 511u];                        // table index k + 160, k = kb - 127
+    const int eb = (int)kb + (mant > win ? 1 : 0);                        // biased shared exponent
+    const int emb = eb - mant_bits;                                       // biased exponent of the interval
+    bool ok = (kb >= 1u) && (kb <= 254u) && (emb >= 1) && (emb <= 253) && (eb <= 254);
+    if constexpr (DT == BFPQ_F16) ok = ok && (emb >= 103) && (eb <= 142); // 2^-24 <= interval, 2^e finite in fp16
+    f.ok = ok;
+    f.interval = u2f((uint32_t)emb << 23);
+    f.inv = u2f((uint32_t)(254 - emb) << 23);
+    f.qmax = (float)((1u << mant_bits) - 1u);
+    f.e = eb - 127;
+    return f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_fused_flat: the tensor is a flat array of 16-byte lane items; rows do not matter because
+// cols % block == 0 (and cols % M == 0).  NM in {0,2,4}.  One HBM read, one HBM write per output.
+//   hot path per item: [packed 3-way comparisons -> 729-entry LDS table -> AND masks], packed abs/max,
+//   DPP group max, exponent from a 320-byte LDS table, mul / rndne / med3 / mul per element, pack.
+//   Anything unusual in a block (non-finite or zero max, scale outside the normal range, mantissa
+//   wider than the dtype) makes the whole wavefront replay that item through the step-by-step
+//   emulation (quant_elem); the branch is wave-uniform and never taken on ordinary weights.
+// ---------------------------------------------------------------------------------------------
+template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT>
+__global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
+{
+    using T = Traits<DT>;
+    constexpr int VEC = T::VEC;
+    __shared__ uint8_t s_win[512];
+    __shared__ uint2 s_mask[NM == 4 && VEC == 8 ? 736 : 1];      // 16-bit dtypes: AND masks for the two dwords of a group
+    __shared__ uint8_t s_keep[NM == 4 && VEC == 4 ? 736 : 1];    // fp32: 4-bit keep mask
+    for (int i = threadIdx.x; i < 512; i += kThreads)
+        s_win[i] = (a.exp_win && i < BFPQ_EXP_WIN_ENTRIES) ? a.exp_win[i] : 0;
+    if constexpr (NM == 4) {
+        for (int i = threadIdx.x; i < BFPQ_NM4_LUT_ENTRIES; i += kThreads) {
+            const uint32_t k = a.nm_lut[i];
+            if constexpr (VEC == 8)
+                s_mask[i] = make_uint2(((k & 1u) ? 0xffffu : 0u) | ((k & 2u) ? 0xffff0000u : 0u),
+                                       ((k & 4u) ? 0xffffu : 0u) | ((k & 8u) ? 0xffff0000u : 0u));
+            else s_keep[i] = (uint8_t)k;
+        }
+    }
+    __syncthreads();
+
+    const bool do_quant = a.lpb > 0;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    const int64_t n_round = (a.n_items + kThreads - 1) / kThreads * kThreads;   // uniform trip count per block
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(a.in);
+
+    // N:M mask on the 4 dwords of an item (16-bit dtypes: 2 groups of 4; fp32: 1 group)
+    auto nm_mask = [&](uint32_t& d0, uint32_t& d1, uint32_t& d2, uint32_t& d3) {
+        if constexpr (NM == 4 && VEC == 8) {
+            // A_i = (group0.elem_i | group1.elem_i << 16): both groups go through one packed instruction
+            const uint32_t absm = T::ABS | (T::ABS << 16), nanc = (T::INF + 1u) | ((T::INF + 1u) << 16);
+            auto key = [&](uint32_t hi, uint32_t lo, uint32_t sel) {      // keys <= 0x7fff: signed min == unsigned min
+                return pk_min_i16(__builtin_amdgcn_perm(hi, lo, sel) & absm, nanc);
+            };
+            const uint32_t k0 = key(d2, d0, 0x05040100u), k1 = key(d2, d0, 0x07060302u);
+            const uint32_t k2 = key(d3, d1, 0x05040100u), k3 = key(d3, d1, 0x07060302u);
+            // 3-way comparison of both groups at once: clamp(k_i - k_j, -1, 1); index = 364 + sum c_p 3^p
+            auto c3 = [&](uint32_t x, uint32_t y) { return pk_min_i16(pk_max_i16(pk_sub_i16(x, y), 0xffffffffu), 0x00010001u); };
+            uint32_t ip = pk_mad_i16(c3(k0, k1), 0x00010001u, 0x016c016cu);
+            ip = pk_mad_i16(c3(k0, k2), 0x00030003u, ip);
+            ip = pk_mad_i16(c3(k0, k3), 0x00090009u, ip);
+            ip = pk_mad_i16(c3(k1, k2), 0x001b001bu, ip);
+            ip = pk_mad_i16(c3(k1, k3), 0x00510051u, ip);
+            ip = pk_mad_i16(c3(k2, k3), 0x00f300f3u, ip);
+            const uint2 m0 = s_mask[ip & 0xffffu], m1 = s_mask[ip >> 16];
+            d0 &= m0.x; d1 &= m0.y; d2 &= m1.x; d3 &= m1.y;
+        } else if constexpr (NM == 4) {
+            const uint32_t keep = s_keep[nm4_index(mag_key<DT>(d0), mag_key<DT>(d1), mag_key<DT>(d2), mag_key<DT>(d3))];
+            d0 = (keep & 1u) ? d0 : 0u; d1 = (keep & 2u) ? d1 : 0u; d2 = (keep & 4u) ? d2 : 0u; d3 = (keep & 8u) ? d3 : 0u;
+        } else if constexpr (NM == 2 && VEC == 8) {
+            auto pair = [&](uint32_t& d) {
+                const uint32_t keep = nm2_keep(mag_key<DT>(d & 0xffffu), mag_key<DT>(d >> 16), a.N);
+                d &= ((keep & 1u) ? 0xffffu : 0u) | ((keep & 2u) ? 0xffff0000u : 0u);
+            };
+            pair(d0); pair(d1); pair(d2); pair(d3);
+        } else if constexpr (NM == 2) {
+            const uint32_t ka = nm2_keep(mag_key<DT>(d0), mag_key<DT>(d1), a.N), kb2 = nm2_keep(mag_key<DT>(d2), mag_key<DT>(d3), a.N);
+            d0 = (ka & 1u) ? d0 : 0u; d1 = (ka & 2u) ? d1 : 0u; d2 = (kb2 & 1u) ? d2 : 0u; d3 = (kb2 & 2u) ? d3 : 0u;
+        }
+    };
+
+    // Loads are unconditional (index clamped to the last item) so that the prefetch below stays in
+    // flight across the body: a load inside a branch makes hipcc wait vmcnt(0) right after issuing it.
+    int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t last = a.n_items - 1;
+    uint4 cur = src[item < last ? item : last];
+    for (; item < n_round; item += stride) {
+        const bool valid = item < a.n_items;
+        const int64_t pf = item + stride;
+        const uint4 nxt = src[pf < last ? pf : last];                          // prefetch the next item
+        uint32_t d0 = cur.x, d1 = cur.y, d2 = cur.z, d3 = cur.w;
+        cur = nxt;
+
+        if constexpr (NM != 0 && SFIRST) nm_mask(d0, d1, d2, d3);             // S before Q (bfp_ops.py:141-144)
+
+        uint32_t o0 = d0, o1 = d1, o2 = d2, o3 = d3;
+        float code[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; j++) code[j] = 0.f;
+        int e_blk = 0;
+        bool nan_blk = false;
+        if (do_quant) {
+            // block max of |v| as integer max of magnitude bits
+            uint32_t mx;
+            if constexpr (VEC == 8) {
+                const uint32_t absm = T::ABS | (T::ABS << 16);
+                const uint32_t mp = pk_max_u16(pk_max_u16(d0 & absm, d1 & absm), pk_max_u16(d2 & absm, d3 & absm));
+                mx = (mp & 0xffffu) > (mp >> 16) ? (mp & 0xffffu) : (mp >> 16);
+            } else {
+                const uint32_t m01 = (d0 & T::ABS) > (d1 & T::ABS) ? (d0 & T::ABS) : (d1 & T::ABS);
+                const uint32_t m23 = (d2 & T::ABS) > (d3 & T::ABS) ? (d2 & T::ABS) : (d3 & T::ABS);
+                mx = m01 > m23 ? m01 : m23;
+            }
+            mx = group_max<LPBT>(mx, a.lpb);
+            const FastScale fs = fast_scale<DT>(mx, a.mant_bits, a.eps_dt, s_win);
+            e_blk = fs.e;
+            uint32_t raw[VEC];
+            if constexpr (VEC == 4) { raw[0] = d0; raw[1] = d1; raw[2] = d2; raw[3] = d3; }
+            else {
+                raw[0] = d0 & 0xffffu; raw[1] = d0 >> 16; raw[2] = d1 & 0xffffu; raw[3] = d1 >> 16;
+                raw[4] = d2 & 0xffffu; raw[5] = d2 >> 16; raw[6] = d3 & 0xffffu; raw[7] = d3 >> 16;
+            }
+            const bool slow = (a.force_slow != 0) || !fs.ok;
+            if (__builtin_expect(__any(slow), 0)) {
+                // cold: replay the reference's op sequence step by step (exact for every block)
+                const BlockScale bs = block_scale<DT>(mx, a.mant_bits, a.eps_dt, s_win);
+                e_blk = bs.e;
+                nan_blk = bs.mode == 2;
+                uint32_t outraw[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; j++) {
+                    const float dither = STOCH ? uniform24(a.seed, (uint64_t)item * VEC + j) - 0.5f : 0.f;
+                    const float yv = quant_elem<DT>(raw_to_f32<DT>(raw[j]), bs, STOCH, dither, &code[j]);
+                    outraw[j] = f32_to_raw<DT>(yv);
+                }
+                if constexpr (VEC == 4) { o0 = outraw[0]; o1 = outraw[1]; o2 = outraw[2]; o3 = outraw[3]; }
+                else {
+                    o0 = outraw[0] | (outraw[1] << 16); o1 = outraw[2] | (outraw[3] << 16);
+                    o2 = outraw[4] | (outraw[5] << 16); o3 = outraw[6] | (outraw[7] << 16);
+                }
+            } else {
+                float y[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; j++) {
+                    float x;
+                    if constexpr (DT == BFPQ_BF16) x = u2f((j & 1) ? ((j < 2 ? d0 : j < 4 ? d1 : j < 6 ? d2 : d3) & 0xffff0000u) : (raw[j] << 16));
+                    else x = raw_to_f32<DT>(raw[j]);
+                    float t = x * fs.inv;
+                    if constexpr (STOCH) t += uniform24(a.seed, (uint64_t)item * VEC + j) - 0.5f;
+                    float q = rintf(t);
+                    q = __builtin_amdgcn_fmed3f(q, -fs.qmax, fs.qmax);
+                    code[j] = q;
+                    y[j] = q * fs.interval;
+                }
+                if constexpr (DT == BFPQ_F32) { o0 = f2u(y[0]); o1 = f2u(y[1]); o2 = f2u(y[2]); o3 = f2u(y[3]); }
+                else if constexpr (DT == BFPQ_BF16) {                 // exact: the bf16 image is the upper half
+                    o0 = __builtin_amdgcn_perm(f2u(y[1]), f2u(y[0]), 0x07060302u);
+                    o1 = __builtin_amdgcn_perm(f2u(y[3]), f2u(y[2]), 0x07060302u);
+                    o2 = __builtin_amdgcn_perm(f2u(y[5]), f2u(y[4]), 0x07060302u);
+                    o3 = __builtin_amdgcn_perm(f2u(y[7]), f2u(y[6]), 0x07060302u);
+                } else {                                               // exact in fp16: any rounding mode packs it
+                    o0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y[0], y[1]));
+                    o1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y[2], y[3]));
+                    o2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y[4], y[5]));
+                    o3 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y[6], y[7]));
+                }
+            }
+        }
+        if constexpr (NM != 0 && !SFIRST) {                                   // Q before S (bfp_ops.py:146-149)
+            nm_mask(o0, o1, o2, o3);
+            if (a.out_codes) {                                                // a pruned element has code 0
+                if constexpr (VEC == 4) {
+                    code[0] = (o0 & T::ABS) ? code[0] : 0.f; code[1] = (o1 & T::ABS) ? code[1] : 0.f;
+                    code[2] = (o2 & T::ABS) ? code[2] : 0.f; code[3] = (o3 & T::ABS) ? code[3] : 0.f;
+                } else {
+                    const uint32_t od[4] = {o0, o1, o2, o3};
+#pragma unroll
+                    for (int j = 0; j < VEC; j++) code[j] = ((od[j >> 1] >> (16 * (j & 1))) & T::ABS) ? code[j] : 0.f;
+                }
+            }
+        }
+        if (!valid) continue;
+        if (a.out_deq) reinterpret_cast<uint4*>(a.out_deq)[item] = make_uint4(o0, o1, o2, o3);
+        if (a.out_codes) {
+            int c[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; j++) c[j] = (int)code[j];
+            if (a.code_bits == 4) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int j = 0; j < VEC; j++) w |= ((uint32_t)c[j] & 0xfu) << (4 * j);
+                if constexpr (VEC == 8) reinterpret_cast<uint32_t*>(a.out_codes)[item] = w;
+                else reinterpret_cast<uint16_t*>(a.out_codes)[item] = (uint16_t)w;
+            } else if (a.code_bits == 8) {
+                uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) w0 |= ((uint32_t)c[j] & 0xffu) << (8 * j);
+                if constexpr (VEC == 8) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) w1 |= ((uint32_t)c[4 + j] & 0xffu) << (8 * j);
+                    reinterpret_cast<uint2*>(a.out_codes)[item] = make_uint2(w0, w1);
+                } else reinterpret_cast<uint32_t*>(a.out_codes)[item] = w0;
+            } else {
+                uint32_t w[VEC / 2];
+#pragma unroll
+                for (int j = 0; j < VEC / 2; j++) w[j] = ((uint32_t)c[2 * j] & 0xffffu) | (((uint32_t)c[2 * j + 1] & 0xffffu) << 16);
+                if constexpr (VEC == 8) reinterpret_cast<uint4*>(a.out_codes)[item] = make_uint4(w[0], w[1], w[2], w[3]);
+                else reinterpret_cast<uint2*>(a.out_codes)[item] = make_uint2(w[0], w[1]);
+            }
+        }
+        if (a.out_exp && do_quant && (item % a.lpb) == 0) {
+            const int es = e_blk < -127 ? -127 : (e_blk > 127 ? 127 : e_blk);
+            a.out_exp[item / a.lpb] = nan_blk ? (int8_t)-128 : (int8_t)es;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_nm_rows: one thread per N:M group, general M, ragged rows (tail group padded with zeros as
+// F.pad does, bfp_ops.py:79-82).  codes (optional) are zeroed where an element is pruned.
+// ---------------------------------------------------------------------------------------------
+template <int DT>
+__global__ void __launch_bounds__(128) k_nm_rows(const void* in, void* out, void* codes, int code_bits,
+                                                 int64_t rows, int64_t cols, int N, int M)
+{
+    using raw_t = typename Traits<DT>::raw_t;
+    extern __shared__ uint64_t s_kv[];                    // [M][blockDim.x]
+    const int64_t ngrp = (cols + M - 1) / M;
+    const int64_t total = rows * ngrp;
+    const raw_t* src = reinterpret_cast<const raw_t*>(in);
+    raw_t* dst = reinterpret_cast<raw_t*>(out);
+    KvView view{s_kv + threadIdx.x, (int)blockDim.x};
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = g / ngrp, gi = g - row * ngrp;
+        const int64_t c0 = gi * M;
+        const int n = (int)((cols - c0) < M ? (cols - c0) : M);
+        const int64_t base = row * cols + c0;
+        for (int i = 0; i < M; i++) {
+            const uint32_t key = i < n ? mag_key<DT>((uint32_t)src[base + i]) : 0u;
+            view.set(i, ((uint64_t)key << 8) | (uint64_t)i);
+        }
+        const uint64_t prune = nm_prune_mask(view, N, M);
+        for (int i = 0; i < n; i++) {
+            const bool p = (prune >> i) & 1ull;
+            dst[base + i] = p ? (raw_t)0 : src[base + i];
+            if (codes && p) {
+                const int64_t e = base + i;
+                if (code_bits == 4) {
+                    uint8_t* cb = reinterpret_cast<uint8_t*>(codes) + row * ((cols + 1) / 2) + (c0 + i) / 2;
+                    *cb = ((c0 + i) & 1) ? (uint8_t)(*cb & 0x0f) : (uint8_t)(*cb & 0xf0);
+                } else if (code_bits == 8) reinterpret_cast<int8_t*>(codes)[e] = 0;
+                else reinterpret_cast<int16_t*>(codes)[e] = 0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_quant_rows: general HBFP quantizer.  A group of G lanes (power of two, <= 64) owns one block
+// of `block` elements of one row (the tail block of a row is shorter: the zero pad of
+// bfp_ops.py:50-53 does not change the max and is cut off again).
+// ---------------------------------------------------------------------------------------------
+template <int DT>
+__global__ void __launch_bounds__(kThreads) k_quant_rows(const void* in, void* out_deq, void* out_codes, int8_t* out_exp,
+                                                         int64_t rows, int64_t cols, int block, int G,
+                                                         int mant_bits, float eps_dt, int code_bits, uint64_t seed,
+                                                         const uint8_t* exp_win)
+{
+    using T = Traits<DT>;
+    using raw_t = typename T::raw_t;
+    __shared__ uint8_t s_win[BFPQ_EXP_WIN_ENTRIES];
+    for (int i = threadIdx.x; i < BFPQ_EXP_WIN_ENTRIES; i += kThreads) s_win[i] = exp_win[i];
+    __syncthreads();
+    const bool stoch = seed != 0;
+    const int64_t nblk = (cols + block - 1) / block;
+    const int64_t total = rows * nblk;
+    const int64_t groups_per_grid = (int64_t)gridDim.x * kThreads / G;
+    const int lig = threadIdx.x % G;
+    const int64_t total_round = (total + groups_per_grid - 1) / groups_per_grid * groups_per_grid;
+    const raw_t* src = reinterpret_cast<const raw_t*>(in);
+    for (int64_t b = ((int64_t)blockIdx.x * kThreads + threadIdx.x) / G; b < total_round; b += groups_per_grid) {
+        const bool valid = b < total;
+        const int64_t row = valid ? b / nblk : 0, bi = valid ? b - row * nblk : 0;
+        const int64_t c0 = bi * block;
+        const int len = valid ? (int)((cols - c0) < block ? (cols - c0) : block) : 0;
+        const int64_t base = row * cols + c0;
+        uint32_t mx = 0;
+        for (int i = lig; i < len; i += G) { const uint32_t k = (uint32_t)src[base + i] & T::ABS; mx = k > mx ? k : mx; }
+        for (int o = 1; o < G; o <<= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)mx, o, 64); mx = other > mx ? other : mx; }
+        const BlockScale bs = block_scale<DT>(mx, mant_bits, eps_dt, s_win);
+        // two elements per step so that a 4-bit code byte is written by one lane (block is even then)
+        for (int i = 2 * lig; i < len; i += 2 * G) {
+            float c2[2] = {0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (i + h >= len) break;
+                const float dither = stoch ? uniform24(seed, (uint64_t)(base + i + h)) - 0.5f : 0.f;
+                const float yv = quant_elem<DT>(raw_to_f32<DT>((uint32_t)src[base + i + h]), bs, stoch, dither, &c2[h]);
+                if (out_deq) reinterpret_cast<raw_t*>(out_deq)[base + i + h] = (raw_t)f32_to_raw<DT>(yv);
+                if (out_codes && code_bits == 8) reinterpret_cast<int8_t*>(out_codes)[base + i + h] = (int8_t)(int)c2[h];
+                if (out_codes && code_bits == 16) reinterpret_cast<int16_t*>(out_codes)[base + i + h] = (int16_t)(int)c2[h];
+            }
+            if (out_codes && code_bits == 4) {
+                uint8_t* cb = reinterpret_cast<uint8_t*>(out_codes) + row * ((cols + 1) / 2) + (c0 + i) / 2;
+                *cb = (uint8_t)(((uint32_t)(int)c2[0] & 0xfu) | (((uint32_t)(int)c2[1] & 0xfu) << 4));
+            }
+        }
+        if (out_exp && valid && lig == 0) out_exp[b] = sat_exp(bs);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Unstructured: radix select on magnitude keys.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline void select_digit(int dtype, int pass, int* shift, int* nbits)
+{
+    if (dtype == BFPQ_F32) {
+        if (pass == 0) { *shift = 20; *nbits = 11; }
+        else if (pass == 1) { *shift = 9; *nbits = 11; }
+        else { *shift = 0; *nbits = 9; }
+    } else { *shift = 0; *nbits = 15; }
+}
+
+__global__ void k_select_init(bfpq_select_state* st, int64_t k)
+{
+    st->prefix = 0; st->prefix_mask = 0; st->k_rem = k; st->tau = 0; st->done = 0;
+    st->need = 0; st->ties = 0; st->k = k; st->reserved[0] = 0; st->reserved[1] = 0;
+}
+
+template <int DT>
+__global__ void __launch_bounds__(1024) k_select_hist(const void* in, int64_t numel, int shift, int nbits,
+                                                      const bfpq_select_state* st, uint32_t* hist)
+{
+    using T = Traits<DT>;
+    using raw_t = typename T::raw_t;
+    constexpr int VEC = T::VEC;
+    extern __shared__ uint32_t s_hist[];
+    const int nbins = 1 << nbits;
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) s_hist[i] = 0;
+    __syncthreads();
+    const uint32_t pmask = st->prefix_mask, pval = st->prefix;
+    const uint32_t dmask = (uint32_t)nbins - 1u;
+    const raw_t* src = reinterpret_cast<const raw_t*>(in);
+    const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
+    const int64_t n_items = aligned ? numel / VEC : 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < n_items; item += stride) {
+        const uint4 v = reinterpret_cast<const uint4*>(in)[item];
+        uint32_t raw[VEC];
+        if constexpr (VEC == 4) { raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w; }
+        else {
+            raw[0] = v.x & 0xffffu; raw[1] = v.x >> 16; raw[2] = v.y & 0xffffu; raw[3] = v.y >> 16;
+            raw[4] = v.z & 0xffffu; raw[5] = v.z >> 16; raw[6] = v.w & 0xffffu; raw[7] = v.w >> 16;
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+            const uint32_t key = mag_key<DT>(raw[j]);
+            if ((key & pmask) == pval) atomicAdd(&s_hist[(key >> shift) & dmask], 1u);
+        }
+    }
+    for (int64_t i = n_items * VEC + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) {
+        const uint32_t key = mag_key<DT>((uint32_t)src[i]);
+        if ((key & pmask) == pval) atomicAdd(&s_hist[(key >> shift) & dmask], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) {
+        const uint32_t c = s_hist[i];
+        if (c) atomicAdd(&hist[i], c);
+    }
+}
+
+// one block of 1024 threads: first bin whose inclusive prefix count reaches k_rem
+__global__ void __launch_bounds__(1024) k_select_scan(bfpq_select_state* st, const uint32_t* hist, int shift, int nbits, int last)
+{
+    __shared__ unsigned long long s_part[1024];
+    __shared__ int s_bin;
+    __shared__ unsigned long long s_before;
+    const int nbins = 1 << nbits;
+    const int per = (nbins + 1023) / 1024;
+    const int lo = threadIdx.x * per;
+    unsigned long long sum = 0;
+    for (int i = lo; i < lo + per && i < nbins; i++) sum += hist[i];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    // inclusive scan (Hillis-Steele, 1024 entries)
+    for (int o = 1; o < 1024; o <<= 1) {
+        unsigned long long v = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    const unsigned long long k_rem = (unsigned long long)st->k_rem;
+    if (threadIdx.x == 0) { s_bin = nbins - 1; s_before = 0; }
+    __syncthreads();
+    const unsigned long long incl = s_part[threadIdx.x];
+    const unsigned long long excl = incl - sum;
+    if (k_rem > excl && k_rem <= incl) {           // the crossing lies in this thread's chunk
+        unsigned long long run = excl;
+        for (int i = lo; i < lo + per && i < nbins; i++) {
+            const unsigned long long h = hist[i];
+            if (k_rem <= run + h) { s_bin = i; s_before = run; break; }
+            run += h;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t dmask = ((uint32_t)nbins - 1u) << shift;
+        int bin = s_bin;
+        unsigned long long before = s_before;
+        if (k_rem == 0) { bin = 0; before = 0; }
+        st->prefix |= (uint32_t)bin << shift;
+        st->prefix_mask |= dmask;
+        st->k_rem = (int64_t)(k_rem - before);
+        if (last) {
+            st->tau = st->prefix;
+            st->need = st->k_rem;
+            st->ties = (int64_t)hist[bin];
+            st->done = 1;
+        }
+    }
+}
+
+template <int DT> __device__ __forceinline__ void load_raw_vec(const void* in, int64_t item, uint32_t* raw)
+{
+    constexpr int VEC = Traits<DT>::VEC;
+    const uint4 v = reinterpret_cast<const uint4*>(in)[item];
+    if constexpr (VEC == 4) { raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w; }
+    else {
+        raw[0] = v.x & 0xffffu; raw[1] = v.x >> 16; raw[2] = v.y & 0xffffu; raw[3] = v.y >> 16;
+        raw[4] = v.z & 0xffffu; raw[5] = v.z >> 16; raw[6] = v.w & 0xffffu; raw[7] = v.w >> 16;
+    }
+}
+
+// chunk c of BFPQ_TIE_CHUNKS covers elements [c*chunk, (c+1)*chunk), chunk a multiple of 256*VEC
+__host__ __device__ inline int64_t tie_chunk_elems(int64_t numel, int vec)
+{
+    const int64_t tile = (int64_t)kThreads * vec;
+    const int64_t tiles = (numel + tile - 1) / tile;
+    const int64_t per = (tiles + BFPQ_TIE_CHUNKS - 1) / BFPQ_TIE_CHUNKS;
+    return (per > 0 ? per : 1) * tile;
+}
+
+template <int DT>
+__global__ void __launch_bounds__(kThreads) k_tie_count(const void* in, int64_t numel, const bfpq_select_state* st, uint32_t* counts)
+{
+    using T = Traits<DT>;
+    using raw_t = typename T::raw_t;
+    constexpr int VEC = T::VEC;
+    __shared__ uint32_t s_red[kThreads / 64];
+    const int64_t need = st->need, ties = st->ties;
+    if (need == 0 || need == ties) { if (threadIdx.x == 0) counts[blockIdx.x] = 0; return; }   // ranks not needed
+    const uint32_t tau = st->tau;
+    const int64_t chunk = tie_chunk_elems(numel, VEC);
+    const int64_t lo = (int64_t)blockIdx.x * chunk;
+    const int64_t hi = lo + chunk < numel ? lo + chunk : numel;
+    const raw_t* src = reinterpret_cast<const raw_t*>(in);
+    const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
+    uint32_t cnt = 0;
+    for (int64_t t0 = lo; t0 < hi; t0 += (int64_t)kThreads * VEC) {
+        const int64_t e0 = t0 + (int64_t)threadIdx.x * VEC;
+        if (aligned && e0 + VEC <= hi) {
+            uint32_t raw[VEC];
+            load_raw_vec<DT>(in, e0 / VEC, raw);
+#pragma unroll
+            for (int j = 0; j < VEC; j++) cnt += mag_key<DT>(raw[j]) == tau;
+        } else {
+            for (int j = 0; j < VEC; j++) if (e0 + j < hi) cnt += mag_key<DT>((uint32_t)src[e0 + j]) == tau;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t s = 0; for (int w = 0; w < kThreads / 64; w++) s += s_red[w]; counts[blockIdx.x] = s; }
+}
+
+template <int DT>
+__global__ void __launch_bounds__(kThreads) k_threshold_apply(const void* in, void* out, int64_t numel,
+                                                              const bfpq_select_state* st, const uint32_t* counts,
+                                                              const int64_t* tie_base)
+{
+    using T = Traits<DT>;
+    using raw_t = typename T::raw_t;
+    constexpr int VEC = T::VEC;
+    __shared__ uint32_t s_wave[kThreads / 64];
+    __shared__ unsigned long long s_base;
+    const int64_t need = st->need, ties = st->ties, k = st->k;
+    const uint32_t tau = st->tau;
+    const bool ranked = (k > 0) && need != 0 && need != ties;
+    const int64_t chunk = tie_chunk_elems(numel, VEC);
+    const int64_t lo = (int64_t)blockIdx.x * chunk;
+    const int64_t hi = lo + chunk < numel ? lo + chunk : numel;
+    const raw_t* src = reinterpret_cast<const raw_t*>(in);
+    raw_t* dst = reinterpret_cast<raw_t*>(out);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+    if (ranked) {
+        // ties of all earlier chunks (and earlier ranks): this chunk's first tie has that rank
+        unsigned long long b = 0;
+        for (int c = threadIdx.x; c < (int)blockIdx.x; c += kThreads) b += counts[c];
+        for (int o = 32; o > 0; o >>= 1) b += (unsigned long long)__shfl_xor((long long)b, o, 64);
+        if (threadIdx.x == 0) s_base = tie_base ? (unsigned long long)*tie_base : 0ull;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s_base, b);
+        __syncthreads();
+    }
+    unsigned long long base = ranked ? s_base : 0ull;
+    for (int64_t t0 = lo; t0 < hi; t0 += (int64_t)kThreads * VEC) {
+        const int64_t e0 = t0 + (int64_t)threadIdx.x * VEC;
+        uint32_t raw[VEC];
+        const bool full = aligned && e0 + VEC <= hi;
+        if (full) load_raw_vec<DT>(in, e0 / VEC, raw);
+        else {
+#pragma unroll
+            for (int j = 0; j < VEC; j++) raw[j] = (e0 + j < hi) ? (uint32_t)src[e0 + j] : 0u;
+        }
+        uint32_t eq = 0;          // bit j: element j equals tau
+        bool prune[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+            const uint32_t key = mag_key<DT>(raw[j]);
+            const bool in_range = e0 + j < hi;
+            prune[j] = (k > 0) && (key < tau || (key == tau && need == ties));
+            if (in_range && key == tau) eq |= 1u << j;
+        }
+        if (ranked) {
+            const uint32_t mine = __popc(eq);
+            // exclusive scan of `mine` over the 256 threads, in thread order
+            uint32_t incl = mine;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+                if ((threadIdx.x & 63) >= o) incl += up;
+            }
+            __syncthreads();                                   // s_wave reuse across tiles
+            if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+            __syncthreads();
+            uint32_t wave_off = 0, tile_total = 0;
+            for (int w = 0; w < kThreads / 64; w++) {
+                const uint32_t c = s_wave[w];
+                if (w < (int)(threadIdx.x >> 6)) wave_off += c;
+                tile_total += c;
+            }
+            unsigned long long rank = base + wave_off + (incl - mine);
+#pragma unroll
+            for (int j = 0; j < VEC; j++) {
+                if ((eq >> j) & 1u) { prune[j] = rank < (unsigned long long)need; rank++; }
+            }
+            base += tile_total;
+        }
+        if (full) {
+            uint4 o;
+            uint32_t r[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; j++) r[j] = prune[j] ? 0u : raw[j];
+            if constexpr (VEC == 4) o = make_uint4(r[0], r[1], r[2], r[3]);
+            else o = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
+            reinterpret_cast<uint4*>(out)[e0 / VEC] = o;
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; j++) if (e0 + j < hi) dst[e0 + j] = prune[j] ? (raw_t)0 : (raw_t)raw[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host helpers
+// ---------------------------------------------------------------------------------------------
+inline float h_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+inline uint32_t h_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+float h_round_bf16(float f)
+{
+    uint32_t u = h_f2u(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return f;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return h_u2f(u & 0xffff0000u);
+}
+
+// fp32 -> nearest fp16 (ties to even) -> fp32, via exact double arithmetic on the fp16 grid
+float h_round_f16(float f)
+{
+    if (f != f || f == 0.0f) return f;
+    const double a = fabs((double)f);
+    if (a >= 65520.0) return f < 0 ? -INFINITY : INFINITY;
+    int ex;
+    frexp(a, &ex);                               // a = m * 2^ex, m in [0.5, 1)
+    int q = ex - 11;                             // 11 significant bits
+    if (q < -24) q = -24;                        // subnormal grid
+    const double r = nearbyint(ldexp(a, -q));    // default rounding mode: ties to even
+    const double v = ldexp(r, q);
+    return (float)(f < 0 ? -v : v);
+}
+
+float h_round(float f, int dtype) { return dtype == BFPQ_F32 ? f : (dtype == BFPQ_F16 ? h_round_f16(f) : h_round_bf16(f)); }
+
+int dtype_vec(int dtype) { return dtype == BFPQ_F32 ? 4 : 8; }
+int dtype_size(int dtype) { return dtype == BFPQ_F32 ? 4 : 2; }
+bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+
+int grid_for(int64_t work_threads)
+{
+    int64_t g = (work_threads + kThreads - 1) / kThreads;
+    if (g < 1) g = 1;
+    return (int)(g > kMaxGrid ? kMaxGrid : g);
+}
+
+template <int DT, int NM, bool SFIRST, bool STOCH>
+int launch_fused_l(const FusedArgs& a, hipStream_t s)
+{
+    const dim3 grid(grid_for(a.n_items)), block(kThreads);
+    if constexpr (!STOCH && NM != 2) {           // the shapes that matter get a compile-time lane group
+        switch (a.lpb) {
+            case 2: hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, STOCH, 2>), grid, block, 0, s, a); return (int)hipGetLastError();
+            case 4: hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, STOCH, 4>), grid, block, 0, s, a); return (int)hipGetLastError();
+            case 8: hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, STOCH, 8>), grid, block, 0, s, a); return (int)hipGetLastError();
+            case 16: hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, STOCH, 16>), grid, block, 0, s, a); return (int)hipGetLastError();
+            default: break;
+        }
+    }
+    hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, STOCH, -1>), grid, block, 0, s, a);
+    return (int)hipGetLastError();
+}
+
+template <int DT, bool STOCH>
+int launch_fused_s(const FusedArgs& a, int M, bool sfirst, hipStream_t s)
+{
+    if (M == 0) return launch_fused_l<DT, 0, true, STOCH>(a, s);
+    if (M == 2) return sfirst ? launch_fused_l<DT, 2, true, STOCH>(a, s) : launch_fused_l<DT, 2, false, STOCH>(a, s);
+    return sfirst ? launch_fused_l<DT, 4, true, STOCH>(a, s) : launch_fused_l<DT, 4, false, STOCH>(a, s);
+}
+
+template <int DT>
+int launch_fused(const FusedArgs& a, int M, bool sfirst, hipStream_t s)
+{
+    return a.seed ? launch_fused_s<DT, true>(a, M, sfirst, s) : launch_fused_s<DT, false>(a, M, sfirst, s);
+}
+
+int launch_nm_rows(const void* in, void* out, void* codes, int code_bits, int64_t rows, int64_t cols, int dtype, int N, int M, hipStream_t s)
+{
+    const int threads = 128;
+    const int64_t total = rows * ((cols + M - 1) / M);
+    if (total == 0) return 0;
+    int64_t g = (total + threads - 1) / threads;
+    const int grid = (int)(g > 4096 ? 4096 : g);
+    const size_t lds = (size_t)M * threads * sizeof(uint64_t);
+    if (lds > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void*)k_nm_rows<BFPQ_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_nm_rows<BFPQ_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)k_nm_rows<BFPQ_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (dtype == BFPQ_F32) hipLaunchKernelGGL((k_nm_rows<BFPQ_F32>), dim3(grid), dim3(threads), lds, s, in, out, codes, code_bits, rows, cols, N, M);
+    else if (dtype == BFPQ_F16) hipLaunchKernelGGL((k_nm_rows<BFPQ_F16>), dim3(grid), dim3(threads), lds, s, in, out, codes, code_bits, rows, cols, N, M);
+    else hipLaunchKernelGGL((k_nm_rows<BFPQ_BF16>), dim3(grid), dim3(threads), lds, s, in, out, codes, code_bits, rows, cols, N, M);
+    return (int)hipGetLastError();
+}
+
+int launch_quant_rows(const void* in, void* out_deq, void* out_codes, int8_t* out_exp, int64_t rows, int64_t cols, int dtype,
+                      int block, int mant_bits, float eps_dt, int code_bits, uint64_t seed, const uint8_t* exp_win, hipStream_t s)
+{
+    const int64_t total = rows * ((cols + block - 1) / block);
+    if (total == 0) return 0;
+    int G = 1;
+    while (G < 64 && 2 * G < block) G <<= 1;       // two elements per lane per step
+    const int grid = grid_for(total * G);
+    if (dtype == BFPQ_F32) hipLaunchKernelGGL((k_quant_rows<BFPQ_F32>), dim3(grid), dim3(kThreads), 0, s, in, out_deq, out_codes, out_exp, rows, cols, block, G, mant_bits, eps_dt, code_bits, seed, exp_win);
+    else if (dtype == BFPQ_F16) hipLaunchKernelGGL((k_quant_rows<BFPQ_F16>), dim3(grid), dim3(kThreads), 0, s, in, out_deq, out_codes, out_exp, rows, cols, block, G, mant_bits, eps_dt, code_bits, seed, exp_win);
+    else hipLaunchKernelGGL((k_quant_rows<BFPQ_BF16>), dim3(grid), dim3(kThreads), 0, s, in, out_deq, out_codes, out_exp, rows, cols, block, G, mant_bits, eps_dt, code_bits, seed, exp_win);
+    return (int)hipGetLastError();
+}
+
+bool fused_shape_ok(int64_t rows, int64_t cols, int dtype, int block_size, int N, int M)
+{
+    (void)N;
+    const int vec = dtype_vec(dtype);
+    const int64_t numel = rows * cols;
+    if (numel == 0 || numel % vec != 0) return false;
+    if (!(M == 0 || M == 2 || M == 4)) return false;
+    if (M != 0 && cols % M != 0) return false;
+    if (block_size == 0) return M != 0;                              // sparsify only
+    if (cols % block_size != 0 || block_size % vec != 0) return false;
+    const int lpb = block_size / vec;
+    return is_pow2(lpb) && lpb <= 64;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int bfpq_version(void) { return BFPQ_VERSION; }
+
+const char* bfpq_error_string(int code)
+{
+    switch (code) {
+        case 0: return "ok";
+        case BFPQ_E_ARG: return "bfpq: invalid argument";
+        case BFPQ_E_UNSUPPORTED: return "bfpq: unsupported configuration";
+        case BFPQ_E_ALIGN: return "bfpq: pointer not 16-byte aligned";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "bfpq: unknown error";
+    }
+}
+
+int bfpq_exp_window_host(int dtype, uint8_t* table)
+{
+    if (!table || dtype < 0 || dtype > 2) return BFPQ_E_ARG;
+    const int mbits = dtype == BFPQ_F32 ? 23 : (dtype == BFPQ_F16 ? 10 : 7);
+    for (int idx = 0; idx < BFPQ_EXP_WIN_ENTRIES; idx++) {
+        const int k = idx - 160;
+        int win = 0;
+        // e(s) for s = 2^k (1 + j 2^-mbits) is k up to some j and k+1 beyond (monotone): scan j upward
+        for (int j = 1; j < 256 && j < (1 << mbits); j++) {
+            const double s = ldexp(1.0 + ldexp((double)j, -mbits), k);
+            const float l32 = (float)log2(s);                         // fp32 log2, correctly rounded
+            const float l = h_round(l32, dtype);
+            if (ceilf(l) > (float)k) break;
+            win = j;
+        }
+        table[idx] = (uint8_t)win;
+    }
+    return 0;
+}
+
+uint64_t bfpq_nm_prune_mask_host(const uint32_t* keys, int N, int M)
+{
+    if (!keys || !(N > 0 && M > 0 && N <= M && M <= 64)) return 0;
+    uint64_t kv[64];
+    for (int i = 0; i < M; i++) kv[i] = ((uint64_t)keys[i] << 8) | (uint64_t)i;
+    KvView v{kv, 1};
+    return nm_prune_mask(v, N, M);
+}
+
+int bfpq_nm4_lut_host(int N, uint8_t* lut)
+{
+    if (!lut || N < 1 || N > 4) return BFPQ_E_ARG;
+    memset(lut, 0x0f, BFPQ_NM4_LUT_ENTRIES);              // unreachable signatures keep everything
+    for (uint32_t v = 0; v < 256; v++) {                  // every weak ordering of 4 values appears over {0..3}^4
+        const uint32_t k[4] = {v & 3u, (v >> 2) & 3u, (v >> 4) & 3u, (v >> 6) & 3u};
+        auto c3 = [](uint32_t a, uint32_t b) { return (uint32_t)(a > b) + (uint32_t)(a >= b); };
+        const uint32_t idx = c3(k[0], k[1]) + 3u * c3(k[0], k[2]) + 9u * c3(k[0], k[3]) + 27u * c3(k[1], k[2]) +
+                             81u * c3(k[1], k[3]) + 243u * c3(k[2], k[3]);
+        const uint64_t prune = bfpq_nm_prune_mask_host(k, N, 4);
+        lut[idx] = (uint8_t)(~prune & 0xfu);
+    }
+    return 0;
+}
+
+int bfpq_is_fused(int64_t rows, int64_t cols, int dtype, int block_size, int N, int M)
+{
+    if (dtype < 0 || dtype > 2) return 0;
+    return fused_shape_ok(rows, cols, dtype, block_size, N, M) ? 1 : 0;
+}
+
+int bfpq_quantize_nm(const void* in, void* out_deq, void* out_codes, int8_t* out_exp,
+                     int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits, double epsilon,
+                     int N, int M, int sparsify_first, int code_bits, uint64_t stoch_seed,
+                     const uint8_t* exp_win, const uint8_t* nm4_lut, void* scratch, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype < 0 || dtype > 2 || rows < 0 || cols < 0 || block_size < 0) return BFPQ_E_ARG;
+    if (M < 0 || N < 0 || (M > 0 && !(N > 0 && N <= M)) || M > 64) return M > 64 ? BFPQ_E_UNSUPPORTED : BFPQ_E_ARG;
+    if (rows * cols == 0) return 0;
+    if (!in || (!out_deq && !out_codes && !out_exp)) return BFPQ_E_ARG;
+    if (block_size > 0 && (mant_bits < 0 || mant_bits > 23 || !exp_win)) return BFPQ_E_ARG;
+    if (out_codes && !(code_bits == 4 || code_bits == 8 || code_bits == 16)) return BFPQ_E_ARG;
+    if (out_codes && block_size == 0) return BFPQ_E_ARG;
+    if (out_codes && ((code_bits == 4 && mant_bits > 3) || (code_bits == 8 && mant_bits > 7) || (code_bits == 16 && mant_bits > 15))) return BFPQ_E_ARG;
+    if (block_size == 0 && M == 0) return BFPQ_E_ARG;                   // identity: the caller returns its input
+    const float eps_dt = h_round((float)epsilon, dtype);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out_deq) |
+                           reinterpret_cast<uintptr_t>(out_codes)) & 15u) == 0;
+
+    if (aligned && fused_shape_ok(rows, cols, dtype, block_size, N, M) && (M != 4 || nm4_lut)) {
+        FusedArgs a;
+        a.in = in; a.out_deq = out_deq; a.out_codes = out_codes; a.out_exp = out_exp;
+        a.n_items = rows * cols / dtype_vec(dtype);
+        a.exp_win = exp_win; a.nm_lut = nm4_lut; a.seed = stoch_seed; a.eps_dt = eps_dt;
+        a.lpb = block_size ? block_size / dtype_vec(dtype) : 0;
+        a.mant_bits = mant_bits; a.N = N; a.code_bits = code_bits;
+        a.force_slow = mant_bits > (dtype == BFPQ_F32 ? 24 : (dtype == BFPQ_F16 ? 11 : 8));
+        if (dtype == BFPQ_F32) return launch_fused<BFPQ_F32>(a, M, sparsify_first != 0, s);
+        if (dtype == BFPQ_F16) return launch_fused<BFPQ_F16>(a, M, sparsify_first != 0, s);
+        return launch_fused<BFPQ_BF16>(a, M, sparsify_first != 0, s);
+    }
+
+    // general path: separate launches
+    if (out_codes && code_bits == 4 && ((block_size & 1) || (M & 1))) return BFPQ_E_UNSUPPORTED;
+    if (block_size == 0) {                                               // sparsify only
+        if (!out_deq) return BFPQ_E_ARG;
+        return launch_nm_rows(in, out_deq, nullptr, 0, rows, cols, dtype, N, M, s);
+    }
+    if (M == 0)
+        return launch_quant_rows(in, out_deq, out_codes, out_exp, rows, cols, dtype, block_size, mant_bits, eps_dt, code_bits, stoch_seed, exp_win, s);
+    void* tmp = out_deq ? out_deq : scratch;
+    if (!tmp) return BFPQ_E_ARG;
+    int rc;
+    if (sparsify_first) {
+        rc = launch_nm_rows(in, tmp, nullptr, 0, rows, cols, dtype, N, M, s);
+        if (rc) return rc;
+        return launch_quant_rows(tmp, out_deq, out_codes, out_exp, rows, cols, dtype, block_size, mant_bits, eps_dt, code_bits, stoch_seed, exp_win, s);
+    }
+    rc = launch_quant_rows(in, tmp, out_codes, out_exp, rows, cols, dtype, block_size, mant_bits, eps_dt, code_bits, stoch_seed, exp_win, s);
+    if (rc) return rc;
+    return launch_nm_rows(tmp, tmp, out_codes, code_bits, rows, cols, dtype, N, M, s);
+}
+
+int bfpq_nm_sparsify(const void* in, void* out, int64_t rows, int64_t cols, int dtype, int N, int M,
+                     const uint8_t* nm4_lut, void* stream)
+{
+    if (!in || !out || dtype < 0 || dtype > 2 || rows < 0 || cols < 0) return BFPQ_E_ARG;
+    if (!(N > 0 && M > 0 && N <= M)) return BFPQ_E_ARG;
+    if (M > 64) return BFPQ_E_UNSUPPORTED;
+    return bfpq_quantize_nm(in, out, nullptr, nullptr, rows, cols, dtype, 0, 0, 0.0, N, M, 1, 0, 0, nullptr, nm4_lut, nullptr, stream);
+}
+
+int bfpq_select_passes(int dtype) { return dtype == BFPQ_F32 ? 3 : 1; }
+
+int bfpq_select_init(void* state, int64_t k, void* stream)
+{
+    if (!state || k < 0) return BFPQ_E_ARG;
+    hipLaunchKernelGGL(k_select_init, dim3(1), dim3(1), 0, (hipStream_t)stream, (bfpq_select_state*)state, k);
+    return (int)hipGetLastError();
+}
+
+int bfpq_select_hist(const void* in, int64_t numel, int dtype, int pass, const void* state, uint32_t* hist, void* stream)
+{
+    if (!in || !state || !hist || dtype < 0 || dtype > 2 || numel < 0 || pass < 0 || pass >= bfpq_select_passes(dtype)) return BFPQ_E_ARG;
+    int shift, nbits;
+    select_digit(dtype, pass, &shift, &nbits);
+    const size_t lds = sizeof(uint32_t) << nbits;
+    const int threads = 1024;
+    int64_t g = (numel / dtype_vec(dtype) + threads - 1) / threads;
+    const int grid = (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
+    hipStream_t s = (hipStream_t)stream;
+    const bfpq_select_state* st = (const bfpq_select_state*)state;
+    hipError_t err = hipSuccess;
+    if (dtype == BFPQ_F32) {
+        hipLaunchKernelGGL((k_select_hist<BFPQ_F32>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, st, hist);
+    } else if (dtype == BFPQ_F16) {
+        err = hipFuncSetAttribute((const void*)k_select_hist<BFPQ_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return (int)err;
+        hipLaunchKernelGGL((k_select_hist<BFPQ_F16>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, st, hist);
+    } else {
+        err = hipFuncSetAttribute((const void*)k_select_hist<BFPQ_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return (int)err;
+        hipLaunchKernelGGL((k_select_hist<BFPQ_BF16>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, st, hist);
+    }
+    return (int)hipGetLastError();
+}
+
+int bfpq_select_scan(int dtype, int pass, void* state, const uint32_t* hist, void* stream)
+{
+    if (!state || !hist || dtype < 0 || dtype > 2 || pass < 0 || pass >= bfpq_select_passes(dtype)) return BFPQ_E_ARG;
+    int shift, nbits;
+    select_digit(dtype, pass, &shift, &nbits);
+    const int last = pass == bfpq_select_passes(dtype) - 1;
+    hipLaunchKernelGGL(k_select_scan, dim3(1), dim3(1024), 0, (hipStream_t)stream, (bfpq_select_state*)state, hist, shift, nbits, last);
+    return (int)hipGetLastError();
+}
+
+int bfpq_tie_count(const void* in, int64_t numel, int dtype, const void* state, uint32_t* counts, void* stream)
+{
+    if (!in || !state || !counts || dtype < 0 || dtype > 2 || numel < 0) return BFPQ_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const bfpq_select_state* st = (const bfpq_select_state*)state;
+    if (dtype == BFPQ_F32) hipLaunchKernelGGL((k_tie_count<BFPQ_F32>), dim3(BFPQ_TIE_CHUNKS), dim3(kThreads), 0, s, in, numel, st, counts);
+    else if (dtype == BFPQ_F16) hipLaunchKernelGGL((k_tie_count<BFPQ_F16>), dim3(BFPQ_TIE_CHUNKS), dim3(kThreads), 0, s, in, numel, st, counts);
+    else hipLaunchKernelGGL((k_tie_count<BFPQ_BF16>), dim3(BFPQ_TIE_CHUNKS), dim3(kThreads), 0, s, in, numel, st, counts);
+    return (int)hipGetLastError();
+}
+
+int bfpq_threshold_apply(const void* in, void* out, int64_t numel, int dtype, const void* state,
+                         const uint32_t* counts, const int64_t* tie_base, void* stream)
+{
+    if (!in || !out || !state || !counts || dtype < 0 || dtype > 2 || numel < 0) return BFPQ_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const bfpq_select_state* st = (const bfpq_select_state*)state;
+    if (dtype == BFPQ_F32) hipLaunchKernelGGL((k_threshold_apply<BFPQ_F32>), dim3(BFPQ_TIE_CHUNKS), dim3(kThreads), 0, s, in, out, numel, st, counts, tie_base);
+    else if (dtype == BFPQ_F16) hipLaunchKernelGGL((k_threshold_apply<BFPQ_F16>), dim3(BFPQ_TIE_CHUNKS), dim3(kThreads), 0, s, in, out, numel, st, counts, tie_base);
+    else hipLaunchKernelGGL((k_threshold_apply<BFPQ_BF16>), dim3(BFPQ_TIE_CHUNKS), dim3(kThreads), 0, s, in, out, numel, st, counts, tie_base);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

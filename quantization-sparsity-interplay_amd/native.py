@@ -1,0 +1,251 @@
+"""ctypes binding of libbfpq.so (include/bfpq.h) for PyTorch-ROCm tensors.
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every byte of arithmetic on the
+hot path happens in the HIP kernels of csrc/bfpq_kernels.hip.  There is NO CPU fallback: if the
+library is missing, or a tensor is not on a ROCm device, the calls raise.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libbfpq.so"
+_lock = threading.Lock()
+_lib = None
+
+F32, F16, BF16 = 0, 1, 2
+DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+
+EXP_WIN_ENTRIES = 320
+NM4_LUT_ENTRIES = 729
+SELECT_STATE_BYTES = 64
+SELECT_HIST_BINS = 32768
+TIE_CHUNKS = 2048
+
+
+class NativeUnavailable(RuntimeError):
+    """libbfpq.so is not built / not loadable, or the tensor is not on a ROCm device."""
+
+
+def lib_path():
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+def build_library(force=False):
+    """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-s"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return lib_path()
+
+
+def load_library():
+    """dlopen libbfpq.so and declare the prototypes of include/bfpq.h.  Raises NativeUnavailable."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = lib_path()
+        if not os.path.exists(path):
+            raise NativeUnavailable(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                    f"or `make -C {os.path.join(_HERE, 'csrc')}`")
+        try:
+            L = ctypes.CDLL(path)
+        except OSError as e:  # pragma: no cover
+            raise NativeUnavailable(f"cannot load {path}: {e}") from e
+        vp, i64, i32, u64, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.c_double
+        L.bfpq_version.restype = i32
+        L.bfpq_error_string.restype = ctypes.c_char_p
+        L.bfpq_error_string.argtypes = [i32]
+        L.bfpq_exp_window_host.argtypes = [i32, vp]
+        L.bfpq_nm4_lut_host.argtypes = [i32, vp]
+        L.bfpq_nm_prune_mask_host.argtypes = [vp, i32, i32]
+        L.bfpq_nm_prune_mask_host.restype = u64
+        L.bfpq_quantize_nm.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, dbl, i32, i32, i32, i32, u64, vp, vp, vp, vp]
+        L.bfpq_is_fused.argtypes = [i64, i64, i32, i32, i32, i32]
+        L.bfpq_nm_sparsify.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp]
+        L.bfpq_select_passes.argtypes = [i32]
+        L.bfpq_select_init.argtypes = [vp, i64, vp]
+        L.bfpq_select_hist.argtypes = [vp, i64, i32, i32, vp, vp, vp]
+        L.bfpq_select_scan.argtypes = [i32, i32, vp, vp, vp]
+        L.bfpq_tie_count.argtypes = [vp, i64, i32, vp, vp, vp]
+        L.bfpq_threshold_apply.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
+        for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
+                     "bfpq_select_passes", "bfpq_select_init", "bfpq_select_hist", "bfpq_select_scan", "bfpq_tie_count",
+                     "bfpq_threshold_apply"):
+            getattr(L, name).restype = i32
+        _lib = L
+        return _lib
+
+
+EXPORTED_SYMBOLS = ("bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host",
+                    "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
+                    "bfpq_select_passes", "bfpq_select_init", "bfpq_select_hist", "bfpq_select_scan",
+                    "bfpq_tie_count", "bfpq_threshold_apply")
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load_library().bfpq_error_string(rc).decode()
+        raise RuntimeError(f"{what}: {msg} (code {rc})")
+
+
+# ---- host-side tables -----------------------------------------------------------------------
+def exp_window_host(dtype):
+    buf = (ctypes.c_uint8 * EXP_WIN_ENTRIES)()
+    check(load_library().bfpq_exp_window_host(DTYPE_CODE[dtype], ctypes.addressof(buf)), "bfpq_exp_window_host")
+    return bytes(buf)
+
+
+def nm4_lut_host(N):
+    buf = (ctypes.c_uint8 * NM4_LUT_ENTRIES)()
+    check(load_library().bfpq_nm4_lut_host(int(N), ctypes.addressof(buf)), "bfpq_nm4_lut_host")
+    return bytes(buf)
+
+
+def nm_prune_mask_host(keys, N, M):
+    arr = (ctypes.c_uint32 * M)(*[int(k) for k in keys])
+    return int(load_library().bfpq_nm_prune_mask_host(ctypes.addressof(arr), int(N), int(M)))
+
+
+_table_cache = {}
+
+
+def _device_table(kind, key, device, maker):
+    ck = (kind, key, device.index if device.index is not None else torch.cuda.current_device())
+    t = _table_cache.get(ck)
+    if t is None:
+        t = torch.frombuffer(bytearray(maker()), dtype=torch.uint8).to(device)
+        _table_cache[ck] = t
+    return t
+
+
+def exp_window_dev(dtype, device):
+    return _device_table("win", dtype, device, lambda: exp_window_host(dtype))
+
+
+def nm4_lut_dev(N, device):
+    return _device_table("lut", int(N), device, lambda: nm4_lut_host(N))
+
+
+# ---- tensor plumbing ------------------------------------------------------------------------
+def require_device_tensor(t, what="tensor"):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{what} must be a torch.Tensor")
+    if t.device.type != "cuda":
+        raise NativeUnavailable(f"{what} is on {t.device}; the BFP engine runs on a ROCm device only (no CPU fallback)")
+    if t.dtype not in DTYPE_CODE:
+        raise TypeError(f"{what} has dtype {t.dtype}; supported: float32, float16, bfloat16")
+
+
+def rows_cols(t):
+    cols = t.shape[-1] if t.dim() > 0 else 1
+    rows = (t.numel() // cols) if cols else 0
+    return rows, cols
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def quantize_nm(t, block_size, mant_bits, epsilon, N=0, M=0, sparsify_first=True, want_deq=True, code_bits=0,
+                want_exp=False, stoch_seed=0, out=None):
+    """Launch bfpq_quantize_nm on t's device/stream.  Returns (deq | None, codes | None, exps | None)."""
+    require_device_tensor(t)
+    L = load_library()
+    src = t.contiguous()
+    rows, cols = rows_cols(src)
+    dev = src.device
+    if src.numel() == 0:                       # nothing to launch; shapes as below
+        nb = (cols + block_size - 1) // block_size if block_size > 0 else 0
+        return (torch.empty_like(src) if want_deq else None,
+                torch.empty((rows, (cols + 1) // 2 if code_bits == 4 else cols), dtype=torch.uint8 if code_bits == 4 else
+                            (torch.int8 if code_bits == 8 else torch.int16), device=dev) if code_bits else None,
+                torch.empty((rows, nb), dtype=torch.int8, device=dev) if (want_exp and block_size > 0) else None)
+    with torch.cuda.device(dev):
+        deq = None
+        if want_deq:
+            deq = out if out is not None else torch.empty_like(src)
+        codes = exps = None
+        if code_bits:
+            if code_bits == 4:
+                codes = torch.empty((rows, (cols + 1) // 2), dtype=torch.uint8, device=dev)
+            elif code_bits == 8:
+                codes = torch.empty((rows, cols), dtype=torch.int8, device=dev)
+            else:
+                codes = torch.empty((rows, cols), dtype=torch.int16, device=dev)
+        if want_exp and block_size > 0:
+            exps = torch.empty((rows, (cols + block_size - 1) // block_size), dtype=torch.int8, device=dev)
+        win = exp_window_dev(src.dtype, dev) if block_size > 0 else None
+        lut = nm4_lut_dev(N, dev) if M == 4 else None
+        fused = L.bfpq_is_fused(rows, cols, DTYPE_CODE[src.dtype], int(block_size), int(N), int(M))
+        scratch = None
+        if not fused and deq is None and M > 0 and block_size > 0:
+            scratch = torch.empty_like(src)
+        rc = L.bfpq_quantize_nm(_ptr(src), _ptr(deq), _ptr(codes), _ptr(exps), rows, cols, DTYPE_CODE[src.dtype],
+                                int(block_size), int(mant_bits), float(epsilon), int(N), int(M),
+                                1 if sparsify_first else 0, int(code_bits), int(stoch_seed),
+                                _ptr(win), _ptr(lut), _ptr(scratch), _stream(src))
+        check(rc, "bfpq_quantize_nm")
+    return deq, codes, exps
+
+
+class SelectWorkspace:
+    """Device scratch of the unstructured path (state + histogram + per-chunk tie counts)."""
+
+    def __init__(self, device):
+        self.state = torch.zeros(SELECT_STATE_BYTES // 8, dtype=torch.int64, device=device)
+        self.hist = torch.zeros(SELECT_HIST_BINS, dtype=torch.int32, device=device)
+        self.tie_counts = torch.zeros(TIE_CHUNKS, dtype=torch.int32, device=device)
+
+    def read_state(self):
+        """host copy of bfpq_select_state (synchronises; for tests / diagnostics only)"""
+        raw = self.state.cpu().numpy().tobytes()
+        import struct
+        prefix, mask, k_rem, tau, done, need, ties, k = struct.unpack_from("<IIqIIqqq", raw, 0)
+        return dict(prefix=prefix, prefix_mask=mask, k_rem=k_rem, tau=tau, done=done, need=need, ties=ties, k=k)
+
+
+def select_threshold(t, k, ws, allreduce=None):
+    """radix-select the k-th smallest magnitude of t (device tensor); leaves the result in ws.state.
+    allreduce: optional callable(hist_tensor) that sums the histogram across ranks in place."""
+    require_device_tensor(t)
+    L = load_library()
+    src = t.contiguous()
+    code = DTYPE_CODE[src.dtype]
+    with torch.cuda.device(src.device):
+        st = _stream(src)
+        check(L.bfpq_select_init(_ptr(ws.state), int(k), st), "bfpq_select_init")
+        for p in range(L.bfpq_select_passes(code)):
+            ws.hist.zero_()
+            check(L.bfpq_select_hist(_ptr(src), src.numel(), code, p, _ptr(ws.state), _ptr(ws.hist), st), "bfpq_select_hist")
+            if allreduce is not None:
+                allreduce(ws.hist)
+            check(L.bfpq_select_scan(code, p, _ptr(ws.state), _ptr(ws.hist), st), "bfpq_select_scan")
+
+
+def threshold_apply(t, ws, out=None, tie_base=None, exchange_ties=None):
+    """zero everything below the threshold in ws.state plus the first `need` ties (flat order).
+    exchange_ties: optional callable(local_tie_total_tensor) -> int64 device tensor with the number of
+    ties held by lower ranks (multi-GPU)."""
+    require_device_tensor(t)
+    L = load_library()
+    src = t.contiguous()
+    code = DTYPE_CODE[src.dtype]
+    with torch.cuda.device(src.device):
+        st = _stream(src)
+        dst = out if out is not None else torch.empty_like(src)
+        check(L.bfpq_tie_count(_ptr(src), src.numel(), code, _ptr(ws.state), _ptr(ws.tie_counts), st), "bfpq_tie_count")
+        if exchange_ties is not None:
+            tie_base = exchange_ties(ws.tie_counts.sum(dtype=torch.int64).reshape(1))
+        check(L.bfpq_threshold_apply(_ptr(src), _ptr(dst), src.numel(), code, _ptr(ws.state), _ptr(ws.tie_counts),
+                                     _ptr(tie_base), st), "bfpq_threshold_apply")
+    return dst
