@@ -1,0 +1,115 @@
+"""Row-sharded execution over the GPUs of one node (one process per GPU, torch.distributed; backend
+'nccl' is RCCL over xGMI on ROCm).
+
+No counterpart in the reference (it has no collectives on this path); the parity contract is
+"gathered result == single-GPU result, byte for byte".
+
+Why rows: every HBFP block and every N:M group lies inside one row (bfp_ops.py:50-59, :79-91), so a
+contiguous slab of rows is an independent unit -- quantize / N:M need NO data-path collective.  The
+only real exchange is unstructured pruning's global k-th magnitude: one all-reduce of the radix
+histogram per pass (128 KB) and one all-gather of per-rank tie totals (8 B per rank).  An all-gather of
+the result happens only when the caller asks for the tensor whole; on a fully connected xGMI node it
+maps to concurrent point-to-point sends, so packed codes (2.9 MB per rank at the headline shape) or
+the dequantised slab (11.3 MB) move at per-link rate on all 7 links at once.
+"""
+import torch
+import torch.distributed as dist
+
+from .bfp import bfp_ops
+from . import native
+
+
+def row_range(rows, world_size, rank):
+    """rows [lo, hi) owned by `rank`: ceil(rows / world) per rank, last ranks may get fewer / none"""
+    per = (rows + world_size - 1) // world_size
+    lo = min(rows, rank * per)
+    return lo, min(rows, lo + per)
+
+
+def shard_rows(t, world_size, rank):
+    """the slab of a [rows, ...] tensor that `rank` owns (a view)"""
+    lo, hi = row_range(t.shape[0], world_size, rank)
+    return t[lo:hi]
+
+
+def all_gather_rows(local, rows_total, group=None):
+    """reassemble a row-sharded tensor on every rank (plain concatenation along dim 0)"""
+    world = dist.get_world_size(group)
+    per = (rows_total + world - 1) // world
+    if per * world == rows_total and local.shape[0] == per:
+        out = torch.empty((rows_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    # ragged: pad every slab to `per` rows, gather, cut
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    out = torch.empty((per * world,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return out[:rows_total]
+
+
+def _hist_allreduce(group):
+    def fn(hist):
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+    return fn
+
+
+def _tie_exchange(group):
+    def fn(local_total):
+        """local_total: int64[1] on the compute device -> int64[1]: ties held by lower ranks"""
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        allt = torch.empty(world, dtype=torch.int64, device=local_total.device)
+        dist.all_gather_into_tensor(allt, local_total.contiguous(), group=group)
+        return allt[:rank].sum().reshape(1)
+    return fn
+
+
+def unstructured_sparsity_sharded(local, sparsity_frac, numel_global, group=None, engine=None):
+    """_unstructured_sparsity (bfp_ops.py:61-71) of a row-sharded tensor: one threshold for the whole
+    tensor, k = int(numel_global * frac), ties pruned lowest global flat index first.
+    engine: object with select_threshold / threshold_apply / workspace (default: the HIP engine)."""
+    assert (sparsity_frac > 0)
+    eng = engine or _NativeEngine()
+    k = int(numel_global * sparsity_frac)
+    ws = eng.workspace(local.device)
+    eng.select_threshold(local, k, ws, allreduce=_hist_allreduce(group))
+    return eng.threshold_apply(local, ws, exchange_ties=_tie_exchange(group)).view(local.shape)
+
+
+class _NativeEngine:
+    def workspace(self, device):
+        return bfp_ops._workspace(device)
+
+    select_threshold = staticmethod(native.select_threshold)
+    threshold_apply = staticmethod(native.threshold_apply)
+
+
+def float_to_bfp_blocked_sharded(local, rows_total, group=None, gather=False, compute=None, engine=None,
+                                 identifier='', **bfp_args):
+    """float_to_bfp_blocked (bfp_ops.py:124-149) on this rank's row slab of a [rows_total, ...] tensor.
+    gather=True reassembles the full fake-quantised tensor on every rank.
+    compute: callable(tensor, **bfp_args, identifier=...) for the per-rank math (default: the HIP engine)."""
+    compute = compute or bfp_ops.float_to_bfp_blocked
+    sparsity = bfp_ops._select_sparsity(bfp_args.get('in_sparsity'), bfp_args.get('w_sparsity'),
+                                        bfp_args.get('grad_sparsity'), identifier)
+    if sparsity and bfp_args.get('sparsity_mode') == 'unstructured':
+        # the one path with a real exchange step: global threshold
+        numel_global = rows_total * (local.numel() // max(local.shape[0], 1))
+        dense = dict(bfp_args, in_sparsity=False, w_sparsity=False, grad_sparsity=False)
+        if bfp_args.get('first') == 's':
+            pruned = unstructured_sparsity_sharded(local, bfp_args['sparsity_frac'], numel_global, group, engine)
+            out = compute(pruned, **dense, identifier=identifier)
+        else:
+            q = compute(local, **dense, identifier=identifier)
+            out = unstructured_sparsity_sharded(q, bfp_args['sparsity_frac'], numel_global, group, engine)
+    else:
+        out = compute(local, **bfp_args, identifier=identifier)
+    return all_gather_rows(out, rows_total, group) if gather else out
+
+
+def float_to_bfp_packed_sharded(local, rows_total, mant_bits, block_size, group=None, gather=False, **kw):
+    """packed codes + exponents of this rank's slab; gather=True all-gathers both (the cheap wire format)"""
+    codes, exps = bfp_ops.float_to_bfp_packed(local, mant_bits, block_size, **kw)
+    if gather:
+        return all_gather_rows(codes, rows_total, group), all_gather_rows(exps, rows_total, group)
+    return codes, exps
