@@ -61,7 +61,8 @@ def cpu_baseline(args, dtype, N, M, cfg_kwargs):
         threads = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    threads = min(threads, int(os.environ.get("BFPQ_CPU_THREADS", "16")))   # a 1-GPU box's CPU share is 16 cores
+    os.environ["OMP_NUM_THREADS"] = str(threads)
     g = torch.Generator().manual_seed(1234)
     w = (torch.randn(args.rows, args.cols, generator=g) * 0.02).to(dtype)
     O.float_to_bfp_blocked(w[:64], **cfg_kwargs, identifier='w')          # build + warm

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
+#include <type_traits>
 #include "bfpq.h"
 #include "bfpq_common.h"
 #include "nm_select.h"
@@ -25,8 +26,35 @@ using namespace bfpq;
 
 namespace {
 
+#ifndef BFPQ_MAXGRID
+#define BFPQ_MAXGRID 1280          // 256 CUs x 5 workgroups, grid-stride beyond that (A/B: 1024-1280 best, 2048 -5 %)
+#endif
+#ifndef BFPQ_NT
+#define BFPQ_NT 1                  // non-temporal loads/stores on the once-touched streams (A/B: +6..8 %)
+#endif
 constexpr int kThreads = 256;
-constexpr int kMaxGrid = 2048;     // 256 CUs x 8 resident workgroups; grid-stride beyond that
+constexpr int kMaxGrid = BFPQ_MAXGRID;
+
+__device__ __forceinline__ uint4 stream_load(const uint4* p)
+{
+#if BFPQ_NT
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void stream_store(uint4* p, uint4 v)
+{
+#if BFPQ_NT
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const u4v w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<u4v*>(p));
+#else
+    *p = v;
+#endif
+}
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers
@@ -58,6 +86,10 @@ __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) { uint32_
 __device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_max_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ uint32_t pk_mad_i16(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+// same with the constant operand in an SGPR (one scalar operand per VALU instruction is allowed)
+__device__ __forceinline__ uint32_t pk_max_i16_s(uint32_t a, uint32_t k) { uint32_t d; asm("v_pk_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k)); return d; }
+__device__ __forceinline__ uint32_t pk_min_i16_s(uint32_t a, uint32_t k) { uint32_t d; asm("v_pk_min_i16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k)); return d; }
+__device__ __forceinline__ uint32_t pk_mad_i16_s(uint32_t a, uint32_t k, uint32_t c) { uint32_t d; asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c)); return d; }
 
 // max over the 2^n adjacent lanes that share one block, by DPP where the ISA has a pattern for it
 template <int CTRL> __device__ __forceinline__ uint32_t dpp_max(uint32_t v)
@@ -139,7 +171,7 @@ __device__ __forceinline__ FastScale fast_scale(uint32_t max_key, int mant_bits,
 //   wider than the dtype) makes the whole wavefront replay that item through the step-by-step
 //   emulation (quant_elem); the branch is wave-uniform and never taken on ordinary weights.
 // ---------------------------------------------------------------------------------------------
-template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT>
+template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY>
 __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
 {
     using T = Traits<DT>;
@@ -166,23 +198,24 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
     const uint4* __restrict__ src = reinterpret_cast<const uint4*>(a.in);
 
     // N:M mask on the 4 dwords of an item (16-bit dtypes: 2 groups of 4; fp32: 1 group)
-    auto nm_mask = [&](uint32_t& d0, uint32_t& d1, uint32_t& d2, uint32_t& d3) {
+    auto nm_mask = [&](uint32_t& d0, uint32_t& d1, uint32_t& d2, uint32_t& d3) __attribute__((always_inline)) {
         if constexpr (NM == 4 && VEC == 8) {
             // A_i = (group0.elem_i | group1.elem_i << 16): both groups go through one packed instruction
             const uint32_t absm = T::ABS | (T::ABS << 16), nanc = (T::INF + 1u) | ((T::INF + 1u) << 16);
             auto key = [&](uint32_t hi, uint32_t lo, uint32_t sel) {      // keys <= 0x7fff: signed min == unsigned min
-                return pk_min_i16(__builtin_amdgcn_perm(hi, lo, sel) & absm, nanc);
+                return pk_min_i16_s(__builtin_amdgcn_perm(hi, lo, sel) & absm, nanc);
             };
             const uint32_t k0 = key(d2, d0, 0x05040100u), k1 = key(d2, d0, 0x07060302u);
             const uint32_t k2 = key(d3, d1, 0x05040100u), k3 = key(d3, d1, 0x07060302u);
             // 3-way comparison of both groups at once: clamp(k_i - k_j, -1, 1); index = 364 + sum c_p 3^p
-            auto c3 = [&](uint32_t x, uint32_t y) { return pk_min_i16(pk_max_i16(pk_sub_i16(x, y), 0xffffffffu), 0x00010001u); };
-            uint32_t ip = pk_mad_i16(c3(k0, k1), 0x00010001u, 0x016c016cu);
-            ip = pk_mad_i16(c3(k0, k2), 0x00030003u, ip);
-            ip = pk_mad_i16(c3(k0, k3), 0x00090009u, ip);
-            ip = pk_mad_i16(c3(k1, k2), 0x001b001bu, ip);
-            ip = pk_mad_i16(c3(k1, k3), 0x00510051u, ip);
-            ip = pk_mad_i16(c3(k2, k3), 0x00f300f3u, ip);
+            auto c3 = [&](uint32_t x, uint32_t y) { return pk_min_i16_s(pk_max_i16_s(pk_sub_i16(x, y), 0xffffffffu), 0x00010001u); };
+            uint32_t ip = 0x016c016cu;
+            ip = pk_mad_i16_s(c3(k0, k1), 0x00010001u, ip);
+            ip = pk_mad_i16_s(c3(k0, k2), 0x00030003u, ip);
+            ip = pk_mad_i16_s(c3(k0, k3), 0x00090009u, ip);
+            ip = pk_mad_i16_s(c3(k1, k2), 0x001b001bu, ip);
+            ip = pk_mad_i16_s(c3(k1, k3), 0x00510051u, ip);
+            ip = pk_mad_i16_s(c3(k2, k3), 0x00f300f3u, ip);
             const uint2 m0 = s_mask[ip & 0xffffu], m1 = s_mask[ip >> 16];
             d0 &= m0.x; d1 &= m0.y; d2 &= m1.x; d3 &= m1.y;
         } else if constexpr (NM == 4) {
@@ -200,18 +233,18 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
         }
     };
 
-    // Loads are unconditional (index clamped to the last item) so that the prefetch below stays in
-    // flight across the body: a load inside a branch makes hipcc wait vmcnt(0) right after issuing it.
-    int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    const int64_t last = a.n_items - 1;
-    uint4 cur = src[item < last ? item : last];
-    for (; item < n_round; item += stride) {
-        const bool valid = item < a.n_items;
-        const int64_t pf = item + stride;
-        const uint4 nxt = src[pf < last ? pf : last];                          // prefetch the next item
+    // One lane item.  GUARD = false in the main loop (every lane of the grid holds a real item: no
+    // branch around any memory operation, so hipcc can emit counted vmcnt waits and keep the prefetches
+    // and the previous store in flight); GUARD = true only in the ragged last sweep.
+    auto body = [&](auto guard_tag, const int64_t item, const uint4 cur) __attribute__((always_inline)) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
+        const bool valid = !GUARD || item < a.n_items;
         uint32_t d0 = cur.x, d1 = cur.y, d2 = cur.z, d3 = cur.w;
-        cur = nxt;
 
+#ifdef BFPQ_COPYONLY          /* A/B knob: same loop, loads and stores only (ceiling for this launch geometry) */
+        if (valid && a.out_deq) stream_store(reinterpret_cast<uint4*>(a.out_deq) + item, make_uint4(d0, d1, d2, d3));
+        return;
+#endif
         if constexpr (NM != 0 && SFIRST) nm_mask(d0, d1, d2, d3);             // S before Q (bfp_ops.py:141-144)
 
         uint32_t o0 = d0, o1 = d1, o2 = d2, o3 = d3;
@@ -260,18 +293,24 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
                     o2 = outraw[4] | (outraw[5] << 16); o3 = outraw[6] | (outraw[7] << 16);
                 }
             } else {
+                typedef float float2v __attribute__((ext_vector_type(2)));
                 float y[VEC];
 #pragma unroll
-                for (int j = 0; j < VEC; j++) {
-                    float x;
-                    if constexpr (DT == BFPQ_BF16) x = u2f((j & 1) ? ((j < 2 ? d0 : j < 4 ? d1 : j < 6 ? d2 : d3) & 0xffff0000u) : (raw[j] << 16));
-                    else x = raw_to_f32<DT>(raw[j]);
-                    float t = x * fs.inv;
-                    if constexpr (STOCH) t += uniform24(a.seed, (uint64_t)item * VEC + j) - 0.5f;
-                    float q = rintf(t);
-                    q = __builtin_amdgcn_fmed3f(q, -fs.qmax, fs.qmax);
-                    code[j] = q;
-                    y[j] = q * fs.interval;
+                for (int j = 0; j < VEC; j += 2) {                     // two elements per v_pk_mul_f32
+                    float2v x;
+                    if constexpr (DT == BFPQ_BF16) {
+                        const uint32_t d = j < 2 ? d0 : (j < 4 ? d1 : (j < 6 ? d2 : d3));
+                        x = (float2v){u2f(d << 16), u2f(d & 0xffff0000u)};
+                    } else x = (float2v){raw_to_f32<DT>(raw[j]), raw_to_f32<DT>(raw[j + 1])};
+                    float2v t = x * (float2v){fs.inv, fs.inv};
+                    if constexpr (STOCH) {
+                        t.x += uniform24(a.seed, (uint64_t)item * VEC + j) - 0.5f;
+                        t.y += uniform24(a.seed, (uint64_t)item * VEC + j + 1) - 0.5f;
+                    }
+                    float2v q = {__builtin_amdgcn_fmed3f(rintf(t.x), -fs.qmax, fs.qmax), __builtin_amdgcn_fmed3f(rintf(t.y), -fs.qmax, fs.qmax)};
+                    code[j] = q.x; code[j + 1] = q.y;
+                    const float2v yy = q * (float2v){fs.interval, fs.interval};
+                    y[j] = yy.x; y[j + 1] = yy.y;
                 }
                 if constexpr (DT == BFPQ_F32) { o0 = f2u(y[0]); o1 = f2u(y[1]); o2 = f2u(y[2]); o3 = f2u(y[3]); }
                 else if constexpr (DT == BFPQ_BF16) {                 // exact: the bf16 image is the upper half
@@ -300,8 +339,12 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
                 }
             }
         }
-        if (!valid) continue;
-        if (a.out_deq) reinterpret_cast<uint4*>(a.out_deq)[item] = make_uint4(o0, o1, o2, o3);
+        if constexpr (DEQ_ONLY) {                                           // hot mode: exactly one store per item
+            if (valid) stream_store(reinterpret_cast<uint4*>(a.out_deq) + item, make_uint4(o0, o1, o2, o3));
+            return;
+        }
+        if (!valid) return;
+        if (a.out_deq) stream_store(reinterpret_cast<uint4*>(a.out_deq) + item, make_uint4(o0, o1, o2, o3));
         if (a.out_codes) {
             int c[VEC];
 #pragma unroll
@@ -333,6 +376,30 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
             const int es = e_blk < -127 ? -127 : (e_blk > 127 ? 127 : e_blk);
             a.out_exp[item / a.lpb] = nan_blk ? (int8_t)-128 : (int8_t)es;
         }
+    };
+
+    // Sweep: item = sweep * stride + global thread id.  Loads run two sweeps ahead of the item being
+    // processed (index clamped to the last item, never conditional).
+    const int64_t last = a.n_items - 1;
+    const int64_t full = a.n_items / stride;                               // sweeps in which every thread has an item
+    int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    auto fetch = [&](int64_t i) __attribute__((always_inline)) { return stream_load(src + (i < last ? i : last)); };
+    uint4 c0 = fetch(item);
+    int64_t sweep = 0;
+    // main loop: load one sweep ahead; unrolled by two so that the two register sets alternate by NAME
+    // (copying a register that a load in flight will write forces vmcnt(0)); with nothing conditional in
+    // the body the waits are counted and the previous store stays in flight across the loop top
+    for (; sweep + 2 <= full; sweep += 2, item += 2 * stride) {
+        const uint4 c1 = fetch(item + stride);
+        body(std::false_type{}, item, c0);
+        c0 = fetch(item + 2 * stride);
+        body(std::false_type{}, item + stride, c1);
+    }
+    // remaining full sweep (0..1) and the ragged last one: guarded, rolled (block-uniform trip count)
+    for (; item < n_round; item += stride) {
+        const uint4 c1 = fetch(item + stride);
+        body(std::true_type{}, item, c0);
+        c0 = c1;
     }
 }
 
@@ -723,21 +790,29 @@ int grid_for(int64_t work_threads)
     return (int)(g > kMaxGrid ? kMaxGrid : g);
 }
 
-template <int DT, int NM, bool SFIRST, bool STOCH>
-int launch_fused_l(const FusedArgs& a, hipStream_t s)
+template <int DT, int NM, bool SFIRST, bool STOCH, bool DEQ_ONLY>
+int launch_fused_o(const FusedArgs& a, hipStream_t s)
 {
     const dim3 grid(grid_for(a.n_items)), block(kThreads);
     if constexpr (!STOCH && NM != 2) {           // the shapes that matter get a compile-time lane group
         switch (a.lpb) {
-            case 2: hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, STOCH, 2>), grid, block, 0, s, a); return (int)hipGetLastError();
-            case 4: hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, STOCH, 4>), grid, block, 0, s, a); return (int)hipGetLastError();
-            case 8: hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, STOCH, 8>), grid, block, 0, s, a); return (int)hipGetLastError();
-            case 16: hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, STOCH, 16>), grid, block, 0, s, a); return (int)hipGetLastError();
+            case 2: hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, STOCH, 2, DEQ_ONLY>), grid, block, 0, s, a); return (int)hipGetLastError();
+            case 4: hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, STOCH, 4, DEQ_ONLY>), grid, block, 0, s, a); return (int)hipGetLastError();
+            case 8: hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, STOCH, 8, DEQ_ONLY>), grid, block, 0, s, a); return (int)hipGetLastError();
+            case 16: hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, STOCH, 16, DEQ_ONLY>), grid, block, 0, s, a); return (int)hipGetLastError();
             default: break;
         }
     }
-    hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, STOCH, -1>), grid, block, 0, s, a);
+    hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, STOCH, -1, DEQ_ONLY>), grid, block, 0, s, a);
     return (int)hipGetLastError();
+}
+
+template <int DT, int NM, bool SFIRST, bool STOCH>
+int launch_fused_l(const FusedArgs& a, hipStream_t s)
+{
+    const bool deq_only = a.out_deq && !a.out_codes && !a.out_exp;
+    if constexpr (!STOCH) if (deq_only) return launch_fused_o<DT, NM, SFIRST, STOCH, true>(a, s);
+    return launch_fused_o<DT, NM, SFIRST, STOCH, false>(a, s);
 }
 
 template <int DT, bool STOCH>

@@ -1,0 +1,115 @@
+// streaming-structure exploration: pure 16 B/lane copy kernels, same buffers/rotation as bench.py
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+#include <string>
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ u4v ld(const u4v* p) { if constexpr (NT) return __builtin_nontemporal_load(p); else return *p; }
+template <bool NT> __device__ __forceinline__ void st(u4v* p, u4v v) { if constexpr (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
+// K0: grid-stride, prefetch distance 1 (the current kernel's loop)
+template <bool NT, int T> __global__ void __launch_bounds__(T) k_gs_pf1(const u4v* in, u4v* out, long n)
+{
+    const long stride = (long)gridDim.x * T, last = n - 1;
+    long item = (long)blockIdx.x * T + threadIdx.x;
+    u4v cur = ld<NT>(in + (item < last ? item : last));
+    for (; item < n; item += stride) {
+        const long pf = item + stride;
+        u4v nxt = ld<NT>(in + (pf < last ? pf : last));
+        st<NT>(out + item, cur);
+        cur = nxt;
+    }
+}
+// K1: contiguous chunk per workgroup, prefetch distance D
+template <bool NT, int T, int D> __global__ void __launch_bounds__(T) k_chunk(const u4v* in, u4v* out, long n)
+{
+    const long per = ((n + gridDim.x - 1) / gridDim.x + T - 1) / T * T;
+    const long lo = (long)blockIdx.x * per, hi = lo + per < n ? lo + per : n, last = n - 1;
+    long item = lo + threadIdx.x;
+    u4v buf[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) { const long p = item + (long)d * T; buf[d] = ld<NT>(in + (p < last ? p : last)); }
+    for (; item < hi; item += (long)D * T) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const long cur = item + (long)d * T;
+            const long p = cur + (long)D * T;
+            u4v v = buf[d];
+            buf[d] = ld<NT>(in + (p < last ? p : last));
+            if (cur < hi) st<NT>(out + cur, v);
+        }
+    }
+}
+// K2: one item per thread, no loop
+template <bool NT, int T> __global__ void __launch_bounds__(T) k_flat(const u4v* in, u4v* out, long n)
+{
+    const long item = (long)blockIdx.x * T + threadIdx.x;
+    if (item < n) st<NT>(out + item, ld<NT>(in + item));
+}
+// K3: grid-stride, U independent items per iteration (all loads first, then stores)
+template <bool NT, int T, int U> __global__ void __launch_bounds__(T) k_gs_u(const u4v* in, u4v* out, long n)
+{
+    const long stride = (long)gridDim.x * T;
+    for (long item = (long)blockIdx.x * T + threadIdx.x; item < n; item += stride * U) {
+        u4v v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) { const long p = item + u * stride; if (p < n) v[u] = ld<NT>(in + p); }
+#pragma unroll
+        for (int u = 0; u < U; u++) { const long p = item + u * stride; if (p < n) st<NT>(out + p, v[u]); }
+    }
+}
+
+struct Var { std::string name; void (*fn)(const u4v*, u4v*, long); int grid, threads; };
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+int main()
+{
+    const long rows = 4096, cols = 11008, n = rows * cols * 2 / 16;
+    const int R = 8, L = 100, ROUNDS = 7;
+    std::vector<u4v*> in(R), out(R);
+    for (int r = 0; r < R; r++) { CK(hipMalloc(&in[r], n * 16)); CK(hipMalloc(&out[r], n * 16)); CK(hipMemset(in[r], r + 1, n * 16)); }
+    std::vector<Var> vars;
+    const int gfull256 = (int)((n + 255) / 256);
+#define ADD(nm, kern, g, t) vars.push_back({nm, kern, g, t})
+    ADD("gs_pf1 g2048", (k_gs_pf1<false, 256>), 2048, 256);
+    ADD("gs_pf1 nt g2048", (k_gs_pf1<true, 256>), 2048, 256);
+    ADD("gs_pf1 nt g1024", (k_gs_pf1<true, 256>), 1024, 256);
+    ADD("gs_pf1 nt g1280", (k_gs_pf1<true, 256>), 1280, 256);
+    ADD("gs_pf1 nt g1024 t512", (k_gs_pf1<true, 512>), 1024, 512);
+    ADD("gs_pf1 nt g512 t512", (k_gs_pf1<true, 512>), 512, 512);
+    ADD("gs_pf1 nt g256 t1024", (k_gs_pf1<true, 1024>), 256, 1024);
+    ADD("gs_pf1 nt g512 t1024", (k_gs_pf1<true, 1024>), 512, 1024);
+    ADD("chunk d1 nt g1024", (k_chunk<true, 256, 1>), 1024, 256);
+    ADD("chunk d2 nt g1024", (k_chunk<true, 256, 2>), 1024, 256);
+    ADD("chunk d4 nt g1024", (k_chunk<true, 256, 4>), 1024, 256);
+    ADD("chunk d2 nt g2048", (k_chunk<true, 256, 2>), 2048, 256);
+    ADD("chunk d2 nt g512", (k_chunk<true, 256, 2>), 512, 256);
+    ADD("chunk d4 nt g512", (k_chunk<true, 256, 4>), 512, 256);
+    ADD("chunk d2 g1024", (k_chunk<false, 256, 2>), 1024, 256);
+    ADD("chunk d2 nt g2752", (k_chunk<true, 256, 2>), 2752, 256);
+    ADD("flat", (k_flat<false, 256>), gfull256, 256);
+    ADD("flat nt", (k_flat<true, 256>), gfull256, 256);
+    ADD("gs_u2 nt g1024", (k_gs_u<true, 256, 2>), 1024, 256);
+    ADD("gs_u4 nt g1024", (k_gs_u<true, 256, 4>), 1024, 256);
+    ADD("gs_u2 nt g2048", (k_gs_u<true, 256, 2>), 2048, 256);
+    ADD("gs_u4 nt g512", (k_gs_u<true, 256, 4>), 512, 256);
+    ADD("gs_u4 g1024", (k_gs_u<false, 256, 4>), 1024, 256);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<std::vector<float>> t(vars.size());
+    for (int round = 0; round < ROUNDS; round++)
+        for (size_t v = 0; v < vars.size(); v++) {
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < L; i++) hipLaunchKernelGGL(vars[v].fn, dim3(vars[v].grid), dim3(vars[v].threads), 0, 0, in[i % R], out[i % R], n);
+            CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (round) t[v].push_back(ms * 1e3f / L);
+        }
+    for (size_t v = 0; v < vars.size(); v++) {
+        std::sort(t[v].begin(), t[v].end());
+        const float med = t[v][t[v].size() / 2];
+        printf("%-24s median %6.2f us min %6.2f  -> %6.0f GB/s (%4.1f%%)\n", vars[v].name.c_str(), med, t[v][0], n * 32.0 / med / 1e3, n * 32.0 / med / 1e3 / 80.0);
+    }
+    // correctness spot check of the last variant family
+    return 0;
+}
