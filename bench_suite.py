@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""bench_suite.py -- per-configuration timings of the hot path on one MI355X (all BASELINE.json configs).
+Not the driver contract (that is bench.py); writes a JSON list to --out and a table to stdout.
+Each case: L launches captured in one hipGraph over R rotating inputs, HIP-event time / L, median of rounds."""
+import argparse, json, os, statistics, sys
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import torch
+import quantization_sparsity_interplay_amd as pkg
+from quantization_sparsity_interplay_amd.bfp import bfp_ops
+
+DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+
+
+def cfg(**kw):
+    base = dict(mant_bits=3, epsilon=1e-8, rounding_mode='determ', device='cuda', block_size=64, num_format='bfp',
+                weight_mant_bits=15, in_sparsity=False, w_sparsity=False, grad_sparsity=False, sparsity_frac=0.5, N=2, M=4,
+                sparsity_num_format='bfp', first='s', sparsity_mode='structured')
+    base.update(kw)
+    return base
+
+
+CASES = [
+    # name, rows, cols, dtype, bytes/elem (algorithmic), callable-maker
+    ("cfg1 OPT-125m [768,768] f32 HBFP8 b32 dense", 768, 768, "f32", 8, dict(mant_bits=7, block_size=32)),
+    ("cfg2 q_proj [4096,4096] bf16 HBFP4 b64 dense", 4096, 4096, "bf16", 4, dict()),
+    ("cfg3 down_proj [4096,11008] bf16 HBFP4 b64 2:4 s (headline)", 4096, 11008, "bf16", 4, dict(w_sparsity=True)),
+    ("cfg3 gate_proj [11008,4096] bf16 HBFP4 b64 2:4 s", 11008, 4096, "bf16", 4, dict(w_sparsity=True)),
+    ("cfg3 down_proj bf16 2:4 q (quantize first)", 4096, 11008, "bf16", 4, dict(w_sparsity=True, first='q')),
+    ("cfg3 down_proj f16 2:4 s", 4096, 11008, "f16", 4, dict(w_sparsity=True)),
+    ("cfg3 down_proj f32 2:4 s", 4096, 11008, "f32", 8, dict(w_sparsity=True)),
+    ("cfg3 down_proj bf16 HBFP8 b64 2:4 s", 4096, 11008, "bf16", 4, dict(w_sparsity=True, mant_bits=7)),
+    ("cfg3 down_proj bf16 2:4 only (fp32 format)", 4096, 11008, "bf16", 4, dict(w_sparsity=True, sparsity_num_format='fp32')),
+    ("cfg4 13B q_proj [5120,5120] bf16 HBFP4 + 50% unstructured s", 5120, 5120, "bf16", 4, dict(w_sparsity=True, sparsity_mode='unstructured')),
+    ("cfg4 13B gate [13824,5120] bf16 HBFP4 + 50% unstructured s", 13824, 5120, "bf16", 4, dict(w_sparsity=True, sparsity_mode='unstructured')),
+    ("cfg4 13B q_proj f32 HBFP4 + 50% unstructured s", 5120, 5120, "f32", 8, dict(w_sparsity=True, sparsity_mode='unstructured')),
+    ("cfg5 ViT-L fc1 [4096,1024] f32 HBFP8 b16 1:4", 4096, 1024, "f32", 8, dict(mant_bits=7, block_size=16, N=1, M=4, w_sparsity=True)),
+    ("cfg5 ViT-L act [8x197,1024] f32 HBFP8 b16 dense (identifier in)", 8 * 197, 1024, "f32", 8, dict(mant_bits=7, block_size=16, N=1, M=4, w_sparsity=True, _ident='in')),
+    ("general path: down_proj bf16 HBFP4 b64 4:8 s (k_nm_rows + k_quant_rows)", 4096, 11008, "bf16", 4, dict(w_sparsity=True, N=4, M=8)),
+    ("general path: [4096,11000] bf16 HBFP4 b64 dense (ragged rows)", 4096, 11000, "bf16", 4, dict()),
+    ("stochastic rounding: down_proj bf16 HBFP4 2:4 s", 4096, 11008, "bf16", 4, dict(w_sparsity=True, rounding_mode='stoc')),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "suite.json"))
+    ap.add_argument("--launches", type=int, default=40)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    results = []
+    for name, rows, cols, dname, bpe, kw in CASES:
+        if args.only and args.only not in name:
+            continue
+        kw = dict(kw)
+        ident = kw.pop("_ident", "w")
+        c = cfg(**kw)
+        dt = DT[dname]
+        numel = rows * cols
+        R = max(2, min(8, int(600e6 // (numel * (4 if dt == torch.float32 else 2))) or 2))
+        ins = [(torch.randn(rows, cols, generator=torch.Generator().manual_seed(1234 + r)) * 0.02).to(dt).to(dev) for r in range(R)]
+        L = args.launches
+
+        def run():
+            for i in range(L):
+                bfp_ops.float_to_bfp_blocked(ins[i % R], **c, identifier=ident)
+        run()
+        torch.cuda.synchronize()
+        mode = "hipGraph"
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                run()
+            replay = g.replay
+        except Exception as e:                                   # not capturable: time the eager path
+            mode = f"eager ({type(e).__name__})"
+            torch.cuda.synchronize()
+            replay = run
+        replay()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(args.rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); replay(); e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3 / L)
+        us = statistics.median(ts)
+        gbps = numel * bpe / us / 1e3
+        results.append(dict(case=name, rows=rows, cols=cols, dtype=dname, us_per_call=us, elems_per_s=numel / us * 1e6,
+                            algorithmic_bytes_per_elem=bpe, achieved_GBps=gbps, frac_of_8TBps=gbps / 8000, launch=mode, rotating_inputs=R))
+        print(f"{name:78s} {us:9.2f} us  {numel/us/1e3:8.1f} Gelem/s  {gbps:7.0f} GB/s ({gbps/80:5.1f}%)  {mode}", flush=True)
+        del ins
+        torch.cuda.empty_cache()
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    json.dump(results, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -101,30 +101,39 @@ int bfpq_nm_sparsify(const void* in_dev, void* out_dev, int64_t rows, int64_t co
  *   1. for pass p in [0, bfpq_select_passes(dtype)):
  *        bfpq_select_hist(...)      per-device histogram of the current digit  -> hist_dev
  *        [all-reduce hist_dev across ranks]
- *        bfpq_select_scan(...)      picks the digit, updates state_dev
- *   2. bfpq_tie_count(...)          elements equal to the threshold per chunk  -> tie_counts_dev
+ *        bfpq_select_scan(..., k)   picks the digit, updates state_dev (pass 0 initialises it with k)
+ *   2. bfpq_tie_count(...)          elements equal to the threshold per chunk  -> tie_ws_dev
  *        [multi-GPU: exchange per-rank totals, pass the sum of lower ranks as tie_base]
  *   3. bfpq_threshold_apply(...)    zeroes every |v| < tau and the first `need` (in flat index
  *                                   order, lower ranks first) of the |v| == tau
- * state_dev: BFPQ_SELECT_STATE_BYTES bytes, hist_dev: BFPQ_SELECT_HIST_BINS uint32 (the caller
- * zeroes hist_dev before every bfpq_select_hist), tie_counts_dev: BFPQ_TIE_CHUNKS uint32.
+ * state_dev: BFPQ_SELECT_STATE_BYTES bytes, hist_dev: BFPQ_SELECT_HIST_BINS uint32 (zero before the
+ * first use; bfpq_select_scan leaves it zeroed again), tie_ws_dev: bfpq_tie_workspace_elems(numel,
+ * dtype) uint32 (after bfpq_tie_count: ties per 64-lane-item tile, and an exclusive prefix over chunks
+ * of 64 tiles; the local total is left in state_dev->reserved[0] for the multi-GPU exchange).
  * k is the global prune count int(numel_global * frac) (bfp_ops.py:66).
  * Tie positions: the reference's are those of a sequential introselect over the whole tensor and
  * are not reproduced; threshold, count and every element outside the tie class are. */
 #define BFPQ_SELECT_STATE_BYTES 64
 #define BFPQ_SELECT_HIST_BINS 32768
-#define BFPQ_TIE_CHUNKS 2048
 
 int bfpq_select_passes(int dtype);
-int bfpq_select_init(void* state_dev, int64_t k, void* stream);
+int64_t bfpq_tie_workspace_elems(int64_t numel, int dtype);
 int bfpq_select_hist(const void* in_dev, int64_t numel, int dtype, int pass,
                      const void* state_dev, uint32_t* hist_dev, void* stream);
-int bfpq_select_scan(int dtype, int pass, void* state_dev, const uint32_t* hist_dev, void* stream);
-int bfpq_tie_count(const void* in_dev, int64_t numel, int dtype, const void* state_dev,
-                   uint32_t* tie_counts_dev, void* stream);
+int bfpq_select_scan(int dtype, int pass, void* state_dev, uint32_t* hist_dev, int64_t k, void* stream);
+int bfpq_tie_count(const void* in_dev, int64_t numel, int dtype, void* state_dev,
+                   uint32_t* tie_ws_dev, void* stream);
 int bfpq_threshold_apply(const void* in_dev, void* out_dev, int64_t numel, int dtype,
-                         const void* state_dev, const uint32_t* tie_counts_dev,
+                         const void* state_dev, const uint32_t* tie_ws_dev,
                          const int64_t* tie_base_dev /* nullable: 0 */, void* stream);
+/* step 3 fused with the quantizer: out = Q(S_threshold(in)) in one pass over the tensor (first == 's',
+ * bfp_ops.py:141-144 with sparsity_mode 'unstructured'); same outputs / tables / fallbacks as
+ * bfpq_quantize_nm (scratch_dev only when the shape needs the two-launch path and out_deq_dev is NULL). */
+int bfpq_quantize_threshold(const void* in_dev, void* out_deq_dev, void* out_codes_dev, int8_t* out_exp_dev,
+                            int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits, double epsilon,
+                            int code_bits, uint64_t stoch_seed, const uint8_t* exp_win_dev,
+                            const void* state_dev, const uint32_t* tie_ws_dev, const int64_t* tie_base_dev,
+                            void* scratch_dev, void* stream);
 
 /* layout of state_dev as read back by a host that wants tau / counts (all little-endian) */
 typedef struct bfpq_select_state {
@@ -135,7 +144,7 @@ typedef struct bfpq_select_state {
     uint32_t done;        /* 1 after the last pass                                               */
     int64_t need;         /* how many elements equal to tau get pruned                           */
     int64_t ties;         /* how many elements equal tau in total                                */
-    int64_t k;            /* the k given to bfpq_select_init                                     */
+    int64_t k;            /* the k given to bfpq_select_scan                                     */
     int64_t reserved[2];
 } bfpq_select_state;
 

@@ -90,6 +90,8 @@ def _unstructured_sparsity(t, device, sparsity_frac=0):
     """reference: bfp_ops.py:61-71 -- zero the int(numel*frac) smallest |v| of the whole tensor"""
     assert (sparsity_frac > 0)
     native.require_device_tensor(t)
+    if t.numel() == 0:
+        return t.clone()
     k = int(t.numel() * sparsity_frac)
     if k > t.numel():
         raise RuntimeError("selected index k out of range")      # what torch.topk raises in the reference
@@ -164,6 +166,21 @@ def float_to_bfp_blocked(t, mant_bits, epsilon, rounding_mode, device, block_siz
         mb = weight_mant_bits if sgd_update else mant_bits
         y, _, _ = native.quantize_nm(t, block_size, mb, epsilon, N=N if N < M else 0, M=M if N < M else 0,
                                      sparsify_first=(first == 's'), stoch_seed=_seed_for(rounding_mode))
+        return _stoc_dtype(y.view(t.shape), rounding_mode)
+
+    if sparsity and sparsity_mode == 'unstructured' and sparsity_num_format == 'bfp' and first == 's':
+        # global threshold (radix select), then prune + quantize in ONE pass over the tensor
+        assert (sparsity_frac > 0)
+        native.require_device_tensor(t)
+        if t.numel() == 0:
+            return t.clone()
+        k = int(t.numel() * sparsity_frac)
+        if k > t.numel():
+            raise RuntimeError("selected index k out of range")
+        mb = weight_mant_bits if sgd_update else mant_bits
+        ws = _workspace(t.device)
+        native.select_threshold(t, k, ws)
+        y, _, _ = native.quantize_threshold(t, ws, block_size, mb, epsilon, stoch_seed=_seed_for(rounding_mode))
         return _stoc_dtype(y.view(t.shape), rounding_mode)
 
     if first == 's':

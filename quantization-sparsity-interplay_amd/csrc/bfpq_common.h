@@ -132,14 +132,16 @@ __device__ __forceinline__ BlockScale block_scale(uint32_t max_key, int mant_bit
     return b;
 }
 
-// counter-based uniform in [0,1) with 24 bits, keyed by (seed, element index)
+// counter-based uniform in [0,1) with 24 bits, keyed by (seed, element index): one round of a
+// 32-bit integer mixer (multiply / xor-shift) over the index -- 9 integer ops, no state
 __device__ __forceinline__ float uniform24(uint64_t seed, uint64_t idx)
 {
-    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (float)(uint32_t)(z >> 40) * 5.9604644775390625e-08f;
+    uint32_t x = (uint32_t)idx * 0x9E3779B9u + (uint32_t)seed;
+    x += (uint32_t)(idx >> 32) * 0x85EBCA6Bu + (uint32_t)(seed >> 32);
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return (float)(x >> 8) * 5.9604644775390625e-08f;
 }
 
 // One element through _convert_blocked_float_to_bfp (:40-44).  Returns the dequantised value

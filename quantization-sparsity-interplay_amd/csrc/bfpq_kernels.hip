@@ -13,7 +13,7 @@
 //   k_quant_rows   general HBFP quantizer (any block size, ragged rows): a power-of-two lane group
 //                  per block, two sweeps (max, then quantize)
 //   k_select_*     radix select of the k-th smallest magnitude (LDS histogram, then a 1-block scan)
-//   k_tie_count / k_threshold_apply   ordered tie handling + zeroing for unstructured pruning
+//   k_tie_count / k_tie_scan / k_threshold_apply   ordered tie ranks + zeroing for unstructured pruning
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
@@ -130,7 +130,105 @@ struct FusedArgs {
     int N;
     int code_bits;
     int force_slow;           // mant_bits wider than the dtype significand: always emulate step by step
+    const bfpq_select_state* sel;   // NM == -1 (global magnitude threshold): select result,
+    const uint32_t* tie_counts;     //   ties per wave-chunk (k_tie_count),
+    const int64_t* tie_base;        //   ties held by lower ranks (nullable)
 };
+
+// wave-level inclusive scan (lane order)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)v, o, 64);
+        if (lane >= o) v += up;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (unsigned long long)__shfl_xor((long long)v, o, 64);
+    return v;
+}
+
+// Tie ranks without block barriers and without a fixed traversal order: the tensor is cut into "wave
+// tiles" of 64 lane items (64 x 16 B, exactly what one wavefront handles per step).  k_tie_count writes
+// the number of threshold ties of every tile, k_tie_scan turns that array into an exclusive prefix (one
+// workgroup; the array is L2-sized), and a consumer wave reads prefix[tile] -- unconditionally, once per
+// tile, so that no load sits inside a branch of the streaming loop -- and adds a wave scan of its own
+// lanes' tie counts when the tile holds a tie at all.
+__host__ __device__ inline int64_t tie_tiles(int64_t n_items) { return (n_items + 63) / 64; }
+// workspace layout (uint32): [0, cpad) exclusive prefix over chunks of 64 tiles; [cpad, cpad + 64*chunks) ties per tile
+struct TieLayout { int64_t n_tiles, n_chunks, cpad; };
+__host__ __device__ inline TieLayout tie_layout(int64_t n_items)
+{
+    TieLayout l;
+    l.n_tiles = tie_tiles(n_items);
+    l.n_chunks = (l.n_tiles + 63) / 64;
+    l.cpad = (l.n_chunks + 63) / 64 * 64;
+    if (l.cpad < 64) l.cpad = 64;
+    return l;
+}
+
+// threshold state as wave-uniform scalars
+struct ThrCtx {
+    uint32_t tau; unsigned long long need, base; bool on, ranked, allties;
+    const uint32_t* coarse; const uint32_t* counts;
+    __device__ __forceinline__ void load(const bfpq_select_state* st, const uint32_t* tie_ws, const int64_t* tie_base, int64_t n_items)
+    {
+        tau = st->tau; need = (unsigned long long)st->need;
+        on = st->k > 0; ranked = on && st->need != 0 && st->need != st->ties; allties = st->need == st->ties;
+        coarse = tie_ws; counts = tie_ws + tie_layout(n_items).cpad;
+        base = tie_base ? (unsigned long long)*tie_base : 0ull;
+    }
+};
+
+// The two unconditional loads a consumer wave makes per tile (nothing is loaded inside a branch of the
+// streaming loop): ties before the tile's chunk of 64 tiles, and this lane's entry of the chunk's counts.
+struct TileTies { uint32_t chunk_prefix, lane_count; };
+__device__ __forceinline__ TileTies tile_ties(int64_t item, const ThrCtx& t)
+{
+    const int64_t tile = item >> 6;
+    TileTies r;
+    r.chunk_prefix = t.coarse[tile >> 6];
+    r.lane_count = t.counts[(tile & ~(int64_t)63) + (threadIdx.x & 63)];
+    return r;
+}
+
+// prune bits of one lane item (bit j = element j goes)
+template <int DT>
+__device__ __forceinline__ uint32_t thr_prune_bits(const uint32_t* raw, bool valid, int64_t item, const TileTies tt, const ThrCtx& t)
+{
+    constexpr int VEC = Traits<DT>::VEC;
+    uint32_t ltm = 0, eqm = 0;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+        const uint32_t key = mag_key<DT>(raw[j]);
+        ltm |= (uint32_t)(key < t.tau) << j;
+        eqm |= (uint32_t)(key == t.tau) << j;
+    }
+    if (!valid) eqm = 0;
+    if (!t.on) return 0;
+    uint32_t prune = ltm;
+    if (t.ranked) {
+        if (__ballot(eqm != 0)) {                          // most wave tiles hold no element equal to tau
+            // ties in the tiles of this chunk that precede this tile: masked wave sum of the chunk's counts
+            const int within = (int)((item >> 6) & 63);
+            uint32_t before = ((int)(threadIdx.x & 63) < within) ? tt.lane_count : 0u;
+            for (int o = 32; o > 0; o >>= 1) before += (uint32_t)__shfl_xor((int)before, o, 64);
+            const uint32_t cnt = __popc(eqm);
+            const uint32_t incl = wave_incl_scan(cnt);
+            unsigned long long r = t.base + tt.chunk_prefix + before + (incl - cnt);
+#pragma unroll
+            for (int j = 0; j < VEC; j++) {
+                if ((eqm >> j) & 1u) { if (r < t.need) prune |= 1u << j; r++; }
+            }
+        }
+    } else if (t.allties) prune |= eqm;
+    return prune;
+}
 
 // scale of a block on the branch-free path; ok == false -> the caller emulates step by step instead
 struct FastScale { float inv, interval, qmax; int e; bool ok; };
@@ -198,8 +296,26 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
     const uint4* __restrict__ src = reinterpret_cast<const uint4*>(a.in);
 
     // N:M mask on the 4 dwords of an item (16-bit dtypes: 2 groups of 4; fp32: 1 group)
+    ThrCtx thr;
+    bool item_valid = true;
+    int64_t item_index = 0;
+    if constexpr (NM == -1) thr.load(a.sel, a.tie_counts, a.tie_base, a.n_items);
     auto nm_mask = [&](uint32_t& d0, uint32_t& d1, uint32_t& d2, uint32_t& d3) __attribute__((always_inline)) {
-        if constexpr (NM == 4 && VEC == 8) {
+        if constexpr (NM == -1) {                       // global magnitude threshold (unstructured, bfp_ops.py:61-71)
+            uint32_t raw[VEC];
+            if constexpr (VEC == 4) { raw[0] = d0; raw[1] = d1; raw[2] = d2; raw[3] = d3; }
+            else {
+                raw[0] = d0 & 0xffffu; raw[1] = d0 >> 16; raw[2] = d1 & 0xffffu; raw[3] = d1 >> 16;
+                raw[4] = d2 & 0xffffu; raw[5] = d2 >> 16; raw[6] = d3 & 0xffffu; raw[7] = d3 >> 16;
+            }
+            const uint32_t prune = thr_prune_bits<DT>(raw, item_valid, item_index, tile_ties(item_index, thr), thr);
+            if constexpr (VEC == 4) {
+                d0 = (prune & 1u) ? 0u : d0; d1 = (prune & 2u) ? 0u : d1; d2 = (prune & 4u) ? 0u : d2; d3 = (prune & 8u) ? 0u : d3;
+            } else {
+                auto m = [](uint32_t pr) { return ((pr & 1u) ? 0u : 0xffffu) | ((pr & 2u) ? 0u : 0xffff0000u); };
+                d0 &= m(prune); d1 &= m(prune >> 2); d2 &= m(prune >> 4); d3 &= m(prune >> 6);
+            }
+        } else if constexpr (NM == 4 && VEC == 8) {
             // A_i = (group0.elem_i | group1.elem_i << 16): both groups go through one packed instruction
             const uint32_t absm = T::ABS | (T::ABS << 16), nanc = (T::INF + 1u) | ((T::INF + 1u) << 16);
             auto key = [&](uint32_t hi, uint32_t lo, uint32_t sel) {      // keys <= 0x7fff: signed min == unsigned min
@@ -239,6 +355,8 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
     auto body = [&](auto guard_tag, const int64_t item, const uint4 cur) __attribute__((always_inline)) {
         constexpr bool GUARD = decltype(guard_tag)::value;
         const bool valid = !GUARD || item < a.n_items;
+        item_valid = valid;
+        item_index = item;
         uint32_t d0 = cur.x, d1 = cur.y, d2 = cur.z, d3 = cur.w;
 
 #ifdef BFPQ_COPYONLY          /* A/B knob: same loop, loads and stores only (ceiling for this launch geometry) */
@@ -381,9 +499,9 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
     // Sweep: item = sweep * stride + global thread id.  Loads run two sweeps ahead of the item being
     // processed (index clamped to the last item, never conditional).
     const int64_t last = a.n_items - 1;
+    auto fetch = [&](int64_t i) __attribute__((always_inline)) { return stream_load(src + (i < last ? i : last)); };
     const int64_t full = a.n_items / stride;                               // sweeps in which every thread has an item
     int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    auto fetch = [&](int64_t i) __attribute__((always_inline)) { return stream_load(src + (i < last ? i : last)); };
     uint4 c0 = fetch(item);
     int64_t sweep = 0;
     // main loop: load one sweep ahead; unrolled by two so that the two register sets alternate by NAME
@@ -509,14 +627,8 @@ __host__ __device__ inline void select_digit(int dtype, int pass, int* shift, in
     } else { *shift = 0; *nbits = 15; }
 }
 
-__global__ void k_select_init(bfpq_select_state* st, int64_t k)
-{
-    st->prefix = 0; st->prefix_mask = 0; st->k_rem = k; st->tau = 0; st->done = 0;
-    st->need = 0; st->ties = 0; st->k = k; st->reserved[0] = 0; st->reserved[1] = 0;
-}
-
 template <int DT>
-__global__ void __launch_bounds__(1024) k_select_hist(const void* in, int64_t numel, int shift, int nbits,
+__global__ void __launch_bounds__(1024) k_select_hist(const void* in, int64_t numel, int shift, int nbits, int first,
                                                       const bfpq_select_state* st, uint32_t* hist)
 {
     using T = Traits<DT>;
@@ -526,24 +638,32 @@ __global__ void __launch_bounds__(1024) k_select_hist(const void* in, int64_t nu
     const int nbins = 1 << nbits;
     for (int i = threadIdx.x; i < nbins; i += blockDim.x) s_hist[i] = 0;
     __syncthreads();
-    const uint32_t pmask = st->prefix_mask, pval = st->prefix;
+    const uint32_t pmask = first ? 0u : st->prefix_mask, pval = first ? 0u : st->prefix;   // pass 0 reads no state
     const uint32_t dmask = (uint32_t)nbins - 1u;
     const raw_t* src = reinterpret_cast<const raw_t*>(in);
     const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
     const int64_t n_items = aligned ? numel / VEC : 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; item < n_items; item += stride) {
-        const uint4 v = reinterpret_cast<const uint4*>(in)[item];
-        uint32_t raw[VEC];
-        if constexpr (VEC == 4) { raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w; }
-        else {
-            raw[0] = v.x & 0xffffu; raw[1] = v.x >> 16; raw[2] = v.y & 0xffffu; raw[3] = v.y >> 16;
-            raw[4] = v.z & 0xffffu; raw[5] = v.z >> 16; raw[6] = v.w & 0xffffu; raw[7] = v.w >> 16;
-        }
+    if (n_items > 0) {
+        // one-ahead prefetch with clamped, unconditional loads (a lone load per wave is latency-bound)
+        const int64_t last = n_items - 1;
+        int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        uint4 v = reinterpret_cast<const uint4*>(in)[item < last ? item : last];
+        for (; item < n_items; item += stride) {
+            const int64_t pf = item + stride;
+            const uint4 nv = reinterpret_cast<const uint4*>(in)[pf < last ? pf : last];
+            uint32_t raw[VEC];
+            if constexpr (VEC == 4) { raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w; }
+            else {
+                raw[0] = v.x & 0xffffu; raw[1] = v.x >> 16; raw[2] = v.y & 0xffffu; raw[3] = v.y >> 16;
+                raw[4] = v.z & 0xffffu; raw[5] = v.z >> 16; raw[6] = v.w & 0xffffu; raw[7] = v.w >> 16;
+            }
 #pragma unroll
-        for (int j = 0; j < VEC; j++) {
-            const uint32_t key = mag_key<DT>(raw[j]);
-            if ((key & pmask) == pval) atomicAdd(&s_hist[(key >> shift) & dmask], 1u);
+            for (int j = 0; j < VEC; j++) {
+                const uint32_t key = mag_key<DT>(raw[j]);
+                if ((key & pmask) == pval) atomicAdd(&s_hist[(key >> shift) & dmask], 1u);
+            }
+            v = nv;
         }
     }
     for (int64_t i = n_items * VEC + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) {
@@ -557,55 +677,80 @@ __global__ void __launch_bounds__(1024) k_select_hist(const void* in, int64_t nu
     }
 }
 
-// one block of 1024 threads: first bin whose inclusive prefix count reaches k_rem
-__global__ void __launch_bounds__(1024) k_select_scan(bfpq_select_state* st, const uint32_t* hist, int shift, int nbits, int last)
+// One block of 1024 threads (16 waves): first bin whose inclusive prefix count reaches k_rem.
+// Wave w owns a contiguous segment of nbins/16 bins, lane l the PER = seg/64 contiguous bins
+// [l*PER, (l+1)*PER) of it -- all of a lane's loads are issued together (one memory latency), the
+// rest is register arithmetic plus one wave scan in the wave that holds the crossing.
+// Leaves the histogram zeroed for the next pass / call.
+template <int PER>
+__global__ void __launch_bounds__(1024) k_select_scan(bfpq_select_state* st, uint32_t* hist, int shift, int nbits, int last, int first, int64_t k_first)
 {
-    __shared__ unsigned long long s_part[1024];
-    __shared__ int s_bin;
-    __shared__ unsigned long long s_before;
+    __shared__ unsigned long long s_tot[16];
     const int nbins = 1 << nbits;
-    const int per = (nbins + 1023) / 1024;
-    const int lo = threadIdx.x * per;
-    unsigned long long sum = 0;
-    for (int i = lo; i < lo + per && i < nbins; i++) sum += hist[i];
-    s_part[threadIdx.x] = sum;
-    __syncthreads();
-    // inclusive scan (Hillis-Steele, 1024 entries)
-    for (int o = 1; o < 1024; o <<= 1) {
-        unsigned long long v = threadIdx.x >= o ? s_part[threadIdx.x - o] : 0;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
+    const int seg = nbins / 16;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool active = lane * PER < seg;                 // seg < 64 (512-bin digit): upper lanes idle
+    uint32_t v[PER];
+    if constexpr (PER % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < PER; j += 4) {
+            const uint4 q = *reinterpret_cast<const uint4*>(hist + w * seg + lane * PER + j);
+            v[j] = q.x; v[j + 1] = q.y; v[j + 2] = q.z; v[j + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER; j++) v[j] = active ? hist[w * seg + lane * PER + j] : 0u;
     }
-    const unsigned long long k_rem = (unsigned long long)st->k_rem;
-    if (threadIdx.x == 0) { s_bin = nbins - 1; s_before = 0; }
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) mine += v[j];
+    const unsigned long long wtot = wave_sum64(mine);
+    if (lane == 0) s_tot[w] = wtot;
     __syncthreads();
-    const unsigned long long incl = s_part[threadIdx.x];
-    const unsigned long long excl = incl - sum;
-    if (k_rem > excl && k_rem <= incl) {           // the crossing lies in this thread's chunk
-        unsigned long long run = excl;
-        for (int i = lo; i < lo + per && i < nbins; i++) {
-            const unsigned long long h = hist[i];
-            if (k_rem <= run + h) { s_bin = i; s_before = run; break; }
-            run += h;
+    // the first pass starts the selection: k comes as an argument, the state is (re)initialised below
+    const unsigned long long k_rem = first ? (unsigned long long)k_first : (unsigned long long)st->k_rem;
+    unsigned long long before = 0;
+    int W = 15;                                          // k_rem beyond the total cannot happen (k <= numel)
+    for (int i = 0; i < 16; i++) {
+        if (k_rem <= before + s_tot[i]) { W = i; break; }
+        if (i < 15) before += s_tot[i];
+    }
+    if (w == W) {
+        const uint32_t incl = wave_incl_scan(mine);       // counts fit 32 bits per wave segment? no: use 64-bit compare below
+        const unsigned long long lane_before = before + (unsigned long long)(incl - mine);
+        const unsigned long long m = __ballot(active && lane_before + mine >= k_rem);
+        int l = m ? __ffsll((long long)m) - 1 : 63;
+        if (k_rem == 0) l = 0;
+        if (lane == l) {
+            unsigned long long run = lane_before;
+            int bin = W * seg + lane * PER + PER - 1;
+            uint32_t tie = v[PER - 1];
+            bool found = false;
+#pragma unroll
+            for (int j = 0; j < PER; j++) {
+                if (!found) {
+                    if (k_rem <= run + v[j]) { bin = W * seg + lane * PER + j; tie = v[j]; found = true; }
+                    else run += v[j];
+                }
+            }
+            if (k_rem == 0) { bin = 0; run = 0; }
+            if (first) {
+                st->prefix = 0; st->prefix_mask = 0; st->tau = 0; st->done = 0; st->need = 0; st->ties = 0;
+                st->k = k_first; st->reserved[0] = 0; st->reserved[1] = 0;
+            }
+            st->prefix |= (uint32_t)bin << shift;
+            st->prefix_mask |= ((uint32_t)nbins - 1u) << shift;
+            st->k_rem = (int64_t)(k_rem - run);
+            if (last) {
+                st->tau = st->prefix;
+                st->need = st->k_rem;
+                st->ties = (int64_t)tie;
+                st->done = 1;
+            }
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t dmask = ((uint32_t)nbins - 1u) << shift;
-        int bin = s_bin;
-        unsigned long long before = s_before;
-        if (k_rem == 0) { bin = 0; before = 0; }
-        st->prefix |= (uint32_t)bin << shift;
-        st->prefix_mask |= dmask;
-        st->k_rem = (int64_t)(k_rem - before);
-        if (last) {
-            st->tau = st->prefix;
-            st->need = st->k_rem;
-            st->ties = (int64_t)hist[bin];
-            st->done = 1;
-        }
-    }
+    for (int i = threadIdx.x; i < nbins; i += 1024) hist[i] = 0;
 }
 
 template <int DT> __device__ __forceinline__ void load_raw_vec(const void* in, int64_t item, uint32_t* raw)
@@ -619,132 +764,129 @@ template <int DT> __device__ __forceinline__ void load_raw_vec(const void* in, i
     }
 }
 
-// chunk c of BFPQ_TIE_CHUNKS covers elements [c*chunk, (c+1)*chunk), chunk a multiple of 256*VEC
-__host__ __device__ inline int64_t tie_chunk_elems(int64_t numel, int vec)
+// item-based grid-stride sweep with a one-ahead prefetch.  FAST: pointer 16-B aligned and numel a
+// multiple of the vector width -> unconditional vector loads (index clamped), so the prefetch stays in
+// flight; otherwise element loads with bounds checks.
+template <int DT, bool FAST>
+__device__ __forceinline__ void sweep_load(const void* in, int64_t item, int64_t n_items, int64_t numel, uint32_t* raw)
 {
-    const int64_t tile = (int64_t)kThreads * vec;
-    const int64_t tiles = (numel + tile - 1) / tile;
-    const int64_t per = (tiles + BFPQ_TIE_CHUNKS - 1) / BFPQ_TIE_CHUNKS;
-    return (per > 0 ? per : 1) * tile;
-}
-
-template <int DT>
-__global__ void __launch_bounds__(kThreads) k_tie_count(const void* in, int64_t numel, const bfpq_select_state* st, uint32_t* counts)
-{
-    using T = Traits<DT>;
-    using raw_t = typename T::raw_t;
-    constexpr int VEC = T::VEC;
-    __shared__ uint32_t s_red[kThreads / 64];
-    const int64_t need = st->need, ties = st->ties;
-    if (need == 0 || need == ties) { if (threadIdx.x == 0) counts[blockIdx.x] = 0; return; }   // ranks not needed
-    const uint32_t tau = st->tau;
-    const int64_t chunk = tie_chunk_elems(numel, VEC);
-    const int64_t lo = (int64_t)blockIdx.x * chunk;
-    const int64_t hi = lo + chunk < numel ? lo + chunk : numel;
-    const raw_t* src = reinterpret_cast<const raw_t*>(in);
-    const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
-    uint32_t cnt = 0;
-    for (int64_t t0 = lo; t0 < hi; t0 += (int64_t)kThreads * VEC) {
-        const int64_t e0 = t0 + (int64_t)threadIdx.x * VEC;
-        if (aligned && e0 + VEC <= hi) {
-            uint32_t raw[VEC];
-            load_raw_vec<DT>(in, e0 / VEC, raw);
+    using raw_t = typename Traits<DT>::raw_t;
+    constexpr int VEC = Traits<DT>::VEC;
+    if constexpr (FAST) load_raw_vec<DT>(in, item < n_items ? item : n_items - 1, raw);
+    else {
+        const int64_t e0 = item * VEC;
 #pragma unroll
-            for (int j = 0; j < VEC; j++) cnt += mag_key<DT>(raw[j]) == tau;
-        } else {
-            for (int j = 0; j < VEC; j++) if (e0 + j < hi) cnt += mag_key<DT>((uint32_t)src[e0 + j]) == tau;
-        }
+        for (int j = 0; j < VEC; j++)                          // past-the-end elements: a key that is never < or == tau
+            raw[j] = (e0 + j < numel) ? (uint32_t)reinterpret_cast<const raw_t*>(in)[e0 + j] : (Traits<DT>::INF + 2u);
     }
-    for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, 64);
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) { uint32_t s = 0; for (int w = 0; w < kThreads / 64; w++) s += s_red[w]; counts[blockIdx.x] = s; }
 }
 
-template <int DT>
+// ties per wave tile (+ their sum per chunk of 64 tiles, integer atomics: deterministic); skipped on the
+// device when ranks are not needed
+template <int DT, bool FAST>
+__global__ void __launch_bounds__(kThreads) k_tie_count(const void* in, int64_t numel, const bfpq_select_state* st, uint32_t* tie_ws)
+{
+    constexpr int VEC = Traits<DT>::VEC;
+    const int64_t n_items = (numel + VEC - 1) / VEC;
+    ThrCtx t; t.load(st, tie_ws, nullptr, n_items);
+    if (!t.ranked) return;
+    uint32_t* counts = tie_ws + tie_layout(n_items).cpad;
+    const int64_t n_round = (n_items + 63) / 64 * 64;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    uint32_t cur[VEC], nxt[VEC];
+    sweep_load<DT, FAST>(in, item, n_items, numel, cur);
+    for (; item < n_round; item += stride) {                   // wave-uniform trip count
+        sweep_load<DT, FAST>(in, item + stride, n_items, numel, nxt);
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < VEC; j++) cnt += mag_key<DT>(cur[j]) == t.tau;
+        if (item >= n_items) cnt = 0;
+        for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, 64);
+        if ((threadIdx.x & 63) == 0) counts[item >> 6] = cnt;
+#pragma unroll
+        for (int j = 0; j < VEC; j++) cur[j] = nxt[j];
+    }
+}
+
+// sum of the 64 tile counts of every chunk: one wave per chunk, coalesced (no memory op inside a branch of
+// k_tie_count's streaming loop: a conditional atomic there tripled its run time)
+__global__ void __launch_bounds__(kThreads) k_tie_chunk_sum(const bfpq_select_state* st, uint32_t* tie_ws, int64_t n_tiles, int64_t n_chunks, int64_t cpad)
+{
+    const bool ranked = st->k > 0 && st->need != 0 && st->need != st->ties;
+    if (!ranked) return;
+    const int64_t c = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
+    if (c >= n_chunks) return;
+    const int64_t tile = c * 64 + (threadIdx.x & 63);
+    uint32_t v = tile < n_tiles ? tie_ws[cpad + tile] : 0u;
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    if ((threadIdx.x & 63) == 0) tie_ws[c] = v;
+}
+
+// exclusive prefix of the per-chunk sums, in place (one workgroup, n = tiles / 64 entries);
+// total -> st->reserved[0]
+__global__ void __launch_bounds__(1024) k_tie_scan(bfpq_select_state* st, uint32_t* coarse, int64_t n)
+{
+    __shared__ unsigned long long s_w[16];
+    const bool ranked = st->k > 0 && st->need != 0 && st->need != st->ties;
+    if (!ranked) { if (threadIdx.x == 0) st->reserved[0] = 0; return; }
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    unsigned long long sum = 0;
+    for (int64_t i = lo; i < hi; i++) sum += coarse[i];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long up = (unsigned long long)__shfl_up((long long)incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    unsigned long long woff = 0, total = 0;
+    for (int i = 0; i < 16; i++) { if (i < w) woff += s_w[i]; total += s_w[i]; }
+    unsigned long long run = woff + incl - sum;
+    for (int64_t i = lo; i < hi; i++) { const uint32_t c = coarse[i]; coarse[i] = (uint32_t)run; run += c; }
+    if (threadIdx.x == 0) st->reserved[0] = (int64_t)total;
+}
+
+template <int DT, bool FAST>
 __global__ void __launch_bounds__(kThreads) k_threshold_apply(const void* in, void* out, int64_t numel,
-                                                              const bfpq_select_state* st, const uint32_t* counts,
+                                                              const bfpq_select_state* st, const uint32_t* tie_ws,
                                                               const int64_t* tie_base)
 {
-    using T = Traits<DT>;
-    using raw_t = typename T::raw_t;
-    constexpr int VEC = T::VEC;
-    __shared__ uint32_t s_wave[kThreads / 64];
-    __shared__ unsigned long long s_base;
-    const int64_t need = st->need, ties = st->ties, k = st->k;
-    const uint32_t tau = st->tau;
-    const bool ranked = (k > 0) && need != 0 && need != ties;
-    const int64_t chunk = tie_chunk_elems(numel, VEC);
-    const int64_t lo = (int64_t)blockIdx.x * chunk;
-    const int64_t hi = lo + chunk < numel ? lo + chunk : numel;
-    const raw_t* src = reinterpret_cast<const raw_t*>(in);
-    raw_t* dst = reinterpret_cast<raw_t*>(out);
-    const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
-    if (ranked) {
-        // ties of all earlier chunks (and earlier ranks): this chunk's first tie has that rank
-        unsigned long long b = 0;
-        for (int c = threadIdx.x; c < (int)blockIdx.x; c += kThreads) b += counts[c];
-        for (int o = 32; o > 0; o >>= 1) b += (unsigned long long)__shfl_xor((long long)b, o, 64);
-        if (threadIdx.x == 0) s_base = tie_base ? (unsigned long long)*tie_base : 0ull;
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0) atomicAdd(&s_base, b);
-        __syncthreads();
-    }
-    unsigned long long base = ranked ? s_base : 0ull;
-    for (int64_t t0 = lo; t0 < hi; t0 += (int64_t)kThreads * VEC) {
-        const int64_t e0 = t0 + (int64_t)threadIdx.x * VEC;
-        uint32_t raw[VEC];
-        const bool full = aligned && e0 + VEC <= hi;
-        if (full) load_raw_vec<DT>(in, e0 / VEC, raw);
-        else {
+    using raw_t = typename Traits<DT>::raw_t;
+    constexpr int VEC = Traits<DT>::VEC;
+    const int64_t n_items = (numel + VEC - 1) / VEC;
+    ThrCtx t; t.load(st, tie_ws, tie_base, n_items);
+    const int64_t n_round = (n_items + 63) / 64 * 64;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    uint32_t cur[VEC], nxt[VEC];
+    sweep_load<DT, FAST>(in, item, n_items, numel, cur);
+    for (; item < n_round; item += stride) {
+        sweep_load<DT, FAST>(in, item + stride, n_items, numel, nxt);
+        const bool valid = item < n_items;
+        const TileTies tt = tile_ties(item, t);
+        const uint32_t prune = thr_prune_bits<DT>(cur, valid, item, tt, t);
+        if (valid) {
+            const int64_t e0 = item * VEC;
+            if constexpr (FAST) {
+                uint32_t r[VEC];
 #pragma unroll
-            for (int j = 0; j < VEC; j++) raw[j] = (e0 + j < hi) ? (uint32_t)src[e0 + j] : 0u;
-        }
-        uint32_t eq = 0;          // bit j: element j equals tau
-        bool prune[VEC];
+                for (int j = 0; j < VEC; j++) r[j] = ((prune >> j) & 1u) ? 0u : cur[j];
+                uint4 o;
+                if constexpr (VEC == 4) o = make_uint4(r[0], r[1], r[2], r[3]);
+                else o = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
+                reinterpret_cast<uint4*>(out)[item] = o;
+            } else {
 #pragma unroll
-        for (int j = 0; j < VEC; j++) {
-            const uint32_t key = mag_key<DT>(raw[j]);
-            const bool in_range = e0 + j < hi;
-            prune[j] = (k > 0) && (key < tau || (key == tau && need == ties));
-            if (in_range && key == tau) eq |= 1u << j;
-        }
-        if (ranked) {
-            const uint32_t mine = __popc(eq);
-            // exclusive scan of `mine` over the 256 threads, in thread order
-            uint32_t incl = mine;
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
-                if ((threadIdx.x & 63) >= o) incl += up;
+                for (int j = 0; j < VEC; j++)
+                    if (e0 + j < numel) reinterpret_cast<raw_t*>(out)[e0 + j] = ((prune >> j) & 1u) ? (raw_t)0 : (raw_t)cur[j];
             }
-            __syncthreads();                                   // s_wave reuse across tiles
-            if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
-            __syncthreads();
-            uint32_t wave_off = 0, tile_total = 0;
-            for (int w = 0; w < kThreads / 64; w++) {
-                const uint32_t c = s_wave[w];
-                if (w < (int)(threadIdx.x >> 6)) wave_off += c;
-                tile_total += c;
-            }
-            unsigned long long rank = base + wave_off + (incl - mine);
-#pragma unroll
-            for (int j = 0; j < VEC; j++) {
-                if ((eq >> j) & 1u) { prune[j] = rank < (unsigned long long)need; rank++; }
-            }
-            base += tile_total;
         }
-        if (full) {
-            uint4 o;
-            uint32_t r[VEC];
 #pragma unroll
-            for (int j = 0; j < VEC; j++) r[j] = prune[j] ? 0u : raw[j];
-            if constexpr (VEC == 4) o = make_uint4(r[0], r[1], r[2], r[3]);
-            else o = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
-            reinterpret_cast<uint4*>(out)[e0 / VEC] = o;
-        } else {
-#pragma unroll
-            for (int j = 0; j < VEC; j++) if (e0 + j < hi) dst[e0 + j] = prune[j] ? (raw_t)0 : (raw_t)raw[j];
-        }
+        for (int j = 0; j < VEC; j++) cur[j] = nxt[j];
     }
 }
 
@@ -783,11 +925,16 @@ int dtype_vec(int dtype) { return dtype == BFPQ_F32 ? 4 : 8; }
 int dtype_size(int dtype) { return dtype == BFPQ_F32 ? 4 : 2; }
 bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// workgroups for `work_threads` grid-stride work items: at most kMaxGrid, and balanced -- every
+// workgroup gets the same number of sweeps (22016 blocks of work -> 18 sweeps x 1224 workgroups, not
+// 1280 workgroups of which 256 do one sweep more)
 int grid_for(int64_t work_threads)
 {
     int64_t g = (work_threads + kThreads - 1) / kThreads;
     if (g < 1) g = 1;
-    return (int)(g > kMaxGrid ? kMaxGrid : g);
+    if (g <= kMaxGrid) return (int)g;
+    const int64_t sweeps = (g + kMaxGrid - 1) / kMaxGrid;
+    return (int)((g + sweeps - 1) / sweeps);
 }
 
 template <int DT, int NM, bool SFIRST, bool STOCH, bool DEQ_ONLY>
@@ -813,6 +960,21 @@ int launch_fused_l(const FusedArgs& a, hipStream_t s)
     const bool deq_only = a.out_deq && !a.out_codes && !a.out_exp;
     if constexpr (!STOCH) if (deq_only) return launch_fused_o<DT, NM, SFIRST, STOCH, true>(a, s);
     return launch_fused_o<DT, NM, SFIRST, STOCH, false>(a, s);
+}
+
+template <int DT>
+int launch_fused_threshold(const FusedArgs& a, hipStream_t s)
+{
+    const dim3 grid(grid_for(a.n_items)), block(kThreads);
+    const bool deq_only = a.out_deq && !a.out_codes && !a.out_exp;
+    if (a.seed) {
+        hipLaunchKernelGGL((k_fused_flat<DT, -1, true, true, -1, false>), grid, block, 0, s, a);
+    } else if (deq_only) {
+        if (a.lpb == 8) hipLaunchKernelGGL((k_fused_flat<DT, -1, true, false, 8, true>), grid, block, 0, s, a);
+        else if (a.lpb == 4) hipLaunchKernelGGL((k_fused_flat<DT, -1, true, false, 4, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_fused_flat<DT, -1, true, false, -1, true>), grid, block, 0, s, a);
+    } else hipLaunchKernelGGL((k_fused_flat<DT, -1, true, false, -1, false>), grid, block, 0, s, a);
+    return (int)hipGetLastError();
 }
 
 template <int DT, bool STOCH>
@@ -973,6 +1135,7 @@ int bfpq_quantize_nm(const void* in, void* out_deq, void* out_codes, int8_t* out
         a.lpb = block_size ? block_size / dtype_vec(dtype) : 0;
         a.mant_bits = mant_bits; a.N = N; a.code_bits = code_bits;
         a.force_slow = mant_bits > (dtype == BFPQ_F32 ? 24 : (dtype == BFPQ_F16 ? 11 : 8));
+        a.sel = nullptr; a.tie_counts = nullptr; a.tie_base = nullptr;
         if (dtype == BFPQ_F32) return launch_fused<BFPQ_F32>(a, M, sparsify_first != 0, s);
         if (dtype == BFPQ_F16) return launch_fused<BFPQ_F16>(a, M, sparsify_first != 0, s);
         return launch_fused<BFPQ_BF16>(a, M, sparsify_first != 0, s);
@@ -1010,13 +1173,6 @@ int bfpq_nm_sparsify(const void* in, void* out, int64_t rows, int64_t cols, int 
 
 int bfpq_select_passes(int dtype) { return dtype == BFPQ_F32 ? 3 : 1; }
 
-int bfpq_select_init(void* state, int64_t k, void* stream)
-{
-    if (!state || k < 0) return BFPQ_E_ARG;
-    hipLaunchKernelGGL(k_select_init, dim3(1), dim3(1), 0, (hipStream_t)stream, (bfpq_select_state*)state, k);
-    return (int)hipGetLastError();
-}
-
 int bfpq_select_hist(const void* in, int64_t numel, int dtype, int pass, const void* state, uint32_t* hist, void* stream)
 {
     if (!in || !state || !hist || dtype < 0 || dtype > 2 || numel < 0 || pass < 0 || pass >= bfpq_select_passes(dtype)) return BFPQ_E_ARG;
@@ -1030,50 +1186,115 @@ int bfpq_select_hist(const void* in, int64_t numel, int dtype, int pass, const v
     const bfpq_select_state* st = (const bfpq_select_state*)state;
     hipError_t err = hipSuccess;
     if (dtype == BFPQ_F32) {
-        hipLaunchKernelGGL((k_select_hist<BFPQ_F32>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, st, hist);
+        hipLaunchKernelGGL((k_select_hist<BFPQ_F32>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, pass == 0, st, hist);
     } else if (dtype == BFPQ_F16) {
         err = hipFuncSetAttribute((const void*)k_select_hist<BFPQ_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return (int)err;
-        hipLaunchKernelGGL((k_select_hist<BFPQ_F16>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, st, hist);
+        hipLaunchKernelGGL((k_select_hist<BFPQ_F16>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, pass == 0, st, hist);
     } else {
         err = hipFuncSetAttribute((const void*)k_select_hist<BFPQ_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return (int)err;
-        hipLaunchKernelGGL((k_select_hist<BFPQ_BF16>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, st, hist);
+        hipLaunchKernelGGL((k_select_hist<BFPQ_BF16>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, pass == 0, st, hist);
     }
     return (int)hipGetLastError();
 }
 
-int bfpq_select_scan(int dtype, int pass, void* state, const uint32_t* hist, void* stream)
+int bfpq_select_scan(int dtype, int pass, void* state, uint32_t* hist, int64_t k, void* stream)
 {
-    if (!state || !hist || dtype < 0 || dtype > 2 || pass < 0 || pass >= bfpq_select_passes(dtype)) return BFPQ_E_ARG;
+    if (!state || !hist || dtype < 0 || dtype > 2 || pass < 0 || pass >= bfpq_select_passes(dtype) || k < 0) return BFPQ_E_ARG;
     int shift, nbits;
     select_digit(dtype, pass, &shift, &nbits);
-    const int last = pass == bfpq_select_passes(dtype) - 1;
-    hipLaunchKernelGGL(k_select_scan, dim3(1), dim3(1024), 0, (hipStream_t)stream, (bfpq_select_state*)state, hist, shift, nbits, last);
+    const int last = pass == bfpq_select_passes(dtype) - 1, first = pass == 0;
+    bfpq_select_state* st = (bfpq_select_state*)state;
+    hipStream_t s = (hipStream_t)stream;
+    const int per = (1 << nbits) / 16 / 64;              // bins per lane: 32 (15-bit digit), 2 (11-bit), 0 -> 1 (9-bit)
+    if (per == 32) hipLaunchKernelGGL(k_select_scan<32>, dim3(1), dim3(1024), 0, s, st, hist, shift, nbits, last, first, k);
+    else if (per == 2) hipLaunchKernelGGL(k_select_scan<2>, dim3(1), dim3(1024), 0, s, st, hist, shift, nbits, last, first, k);
+    else hipLaunchKernelGGL(k_select_scan<1>, dim3(1), dim3(1024), 0, s, st, hist, shift, nbits, last, first, k);
     return (int)hipGetLastError();
 }
 
-int bfpq_tie_count(const void* in, int64_t numel, int dtype, const void* state, uint32_t* counts, void* stream)
+int64_t bfpq_tie_workspace_elems(int64_t numel, int dtype)
 {
-    if (!in || !state || !counts || dtype < 0 || dtype > 2 || numel < 0) return BFPQ_E_ARG;
+    if (dtype < 0 || dtype > 2 || numel < 0) return BFPQ_E_ARG;
+    const int vec = dtype_vec(dtype);
+    const TieLayout l = tie_layout((numel + vec - 1) / vec);
+    return l.cpad + l.n_chunks * 64;
+}
+
+int bfpq_tie_count(const void* in, int64_t numel, int dtype, void* state, uint32_t* tie_ws, void* stream)
+{
+    if (!in || !state || !tie_ws || dtype < 0 || dtype > 2 || numel < 0) return BFPQ_E_ARG;
+    if (numel == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    const bfpq_select_state* st = (const bfpq_select_state*)state;
-    if (dtype == BFPQ_F32) hipLaunchKernelGGL((k_tie_count<BFPQ_F32>), dim3(BFPQ_TIE_CHUNKS), dim3(kThreads), 0, s, in, numel, st, counts);
-    else if (dtype == BFPQ_F16) hipLaunchKernelGGL((k_tie_count<BFPQ_F16>), dim3(BFPQ_TIE_CHUNKS), dim3(kThreads), 0, s, in, numel, st, counts);
-    else hipLaunchKernelGGL((k_tie_count<BFPQ_BF16>), dim3(BFPQ_TIE_CHUNKS), dim3(kThreads), 0, s, in, numel, st, counts);
+    bfpq_select_state* st = (bfpq_select_state*)state;
+    const int vec = dtype_vec(dtype);
+    const int64_t n_items = (numel + vec - 1) / vec;
+    const bool fast = (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && numel % vec == 0;
+    int64_t g = (n_items + kThreads - 1) / kThreads;
+    const dim3 grid((unsigned)(g > 2048 ? 2048 : g)), block(kThreads);
+    const TieLayout lay = tie_layout(n_items);
+#define BFPQ_TC(DT) do { if (fast) hipLaunchKernelGGL((k_tie_count<DT, true>), grid, block, 0, s, in, numel, st, tie_ws); \
+                         else hipLaunchKernelGGL((k_tie_count<DT, false>), grid, block, 0, s, in, numel, st, tie_ws); } while (0)
+    if (dtype == BFPQ_F32) BFPQ_TC(BFPQ_F32); else if (dtype == BFPQ_F16) BFPQ_TC(BFPQ_F16); else BFPQ_TC(BFPQ_BF16);
+#undef BFPQ_TC
+    hipLaunchKernelGGL(k_tie_chunk_sum, dim3((unsigned)((lay.n_chunks + 3) / 4)), dim3(kThreads), 0, s, st, tie_ws, lay.n_tiles, lay.n_chunks, lay.cpad);
+    hipLaunchKernelGGL(k_tie_scan, dim3(1), dim3(1024), 0, s, st, tie_ws, lay.n_chunks);
     return (int)hipGetLastError();
 }
 
 int bfpq_threshold_apply(const void* in, void* out, int64_t numel, int dtype, const void* state,
-                         const uint32_t* counts, const int64_t* tie_base, void* stream)
+                         const uint32_t* tie_ws, const int64_t* tie_base, void* stream)
 {
-    if (!in || !out || !state || !counts || dtype < 0 || dtype > 2 || numel < 0) return BFPQ_E_ARG;
+    if (!in || !out || !state || !tie_ws || dtype < 0 || dtype > 2 || numel < 0) return BFPQ_E_ARG;
+    if (numel == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const bfpq_select_state* st = (const bfpq_select_state*)state;
-    if (dtype == BFPQ_F32) hipLaunchKernelGGL((k_threshold_apply<BFPQ_F32>), dim3(BFPQ_TIE_CHUNKS), dim3(kThreads), 0, s, in, out, numel, st, counts, tie_base);
-    else if (dtype == BFPQ_F16) hipLaunchKernelGGL((k_threshold_apply<BFPQ_F16>), dim3(BFPQ_TIE_CHUNKS), dim3(kThreads), 0, s, in, out, numel, st, counts, tie_base);
-    else hipLaunchKernelGGL((k_threshold_apply<BFPQ_BF16>), dim3(BFPQ_TIE_CHUNKS), dim3(kThreads), 0, s, in, out, numel, st, counts, tie_base);
+    const int vec = dtype_vec(dtype);
+    const bool fast = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0 && numel % vec == 0;
+    const dim3 grid(grid_for((numel + vec - 1) / vec)), block(kThreads);
+#define BFPQ_TA(DT) do { if (fast) hipLaunchKernelGGL((k_threshold_apply<DT, true>), grid, block, 0, s, in, out, numel, st, tie_ws, tie_base); \
+                         else hipLaunchKernelGGL((k_threshold_apply<DT, false>), grid, block, 0, s, in, out, numel, st, tie_ws, tie_base); } while (0)
+    if (dtype == BFPQ_F32) BFPQ_TA(BFPQ_F32); else if (dtype == BFPQ_F16) BFPQ_TA(BFPQ_F16); else BFPQ_TA(BFPQ_BF16);
+#undef BFPQ_TA
     return (int)hipGetLastError();
+}
+
+int bfpq_quantize_threshold(const void* in, void* out_deq, void* out_codes, int8_t* out_exp,
+                            int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits, double epsilon,
+                            int code_bits, uint64_t stoch_seed, const uint8_t* exp_win,
+                            const void* state, const uint32_t* counts, const int64_t* tie_base,
+                            void* scratch, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype < 0 || dtype > 2 || rows < 0 || cols < 0 || block_size <= 0) return BFPQ_E_ARG;
+    if (rows * cols == 0) return 0;
+    if (!in || !state || !counts || !exp_win || (!out_deq && !out_codes && !out_exp)) return BFPQ_E_ARG;
+    if (mant_bits < 0 || mant_bits > 23) return BFPQ_E_ARG;
+    if (out_codes && !(code_bits == 4 || code_bits == 8 || code_bits == 16)) return BFPQ_E_ARG;
+    if (out_codes && ((code_bits == 4 && mant_bits > 3) || (code_bits == 8 && mant_bits > 7) || (code_bits == 16 && mant_bits > 15))) return BFPQ_E_ARG;
+    const float eps_dt = h_round((float)epsilon, dtype);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out_deq) |
+                           reinterpret_cast<uintptr_t>(out_codes)) & 15u) == 0;
+    if (aligned && fused_shape_ok(rows, cols, dtype, block_size, 0, 0)) {
+        FusedArgs a;
+        a.in = in; a.out_deq = out_deq; a.out_codes = out_codes; a.out_exp = out_exp;
+        a.n_items = rows * cols / dtype_vec(dtype);
+        a.exp_win = exp_win; a.nm_lut = nullptr; a.seed = stoch_seed; a.eps_dt = eps_dt;
+        a.lpb = block_size / dtype_vec(dtype);
+        a.mant_bits = mant_bits; a.N = 0; a.code_bits = code_bits;
+        a.force_slow = mant_bits > (dtype == BFPQ_F32 ? 24 : (dtype == BFPQ_F16 ? 11 : 8));
+        a.sel = (const bfpq_select_state*)state; a.tie_counts = counts; a.tie_base = tie_base;
+        if (dtype == BFPQ_F32) return launch_fused_threshold<BFPQ_F32>(a, s);
+        if (dtype == BFPQ_F16) return launch_fused_threshold<BFPQ_F16>(a, s);
+        return launch_fused_threshold<BFPQ_BF16>(a, s);
+    }
+    void* tmp = out_deq ? out_deq : scratch;
+    if (!tmp) return BFPQ_E_ARG;
+    if (out_codes && code_bits == 4 && (block_size & 1)) return BFPQ_E_UNSUPPORTED;
+    int rc = bfpq_threshold_apply(in, tmp, rows * cols, dtype, state, counts, tie_base, stream);
+    if (rc) return rc;
+    return launch_quant_rows(tmp, out_deq, out_codes, out_exp, rows, cols, dtype, block_size, mant_bits, eps_dt, code_bits, stoch_seed, exp_win, s);
 }
 
 }  // extern "C"

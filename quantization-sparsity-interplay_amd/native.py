@@ -23,7 +23,6 @@ EXP_WIN_ENTRIES = 320
 NM4_LUT_ENTRIES = 729
 SELECT_STATE_BYTES = 64
 SELECT_HIST_BINS = 32768
-TIE_CHUNKS = 2048
 
 
 class NativeUnavailable(RuntimeError):
@@ -69,23 +68,25 @@ def load_library():
         L.bfpq_is_fused.argtypes = [i64, i64, i32, i32, i32, i32]
         L.bfpq_nm_sparsify.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp]
         L.bfpq_select_passes.argtypes = [i32]
-        L.bfpq_select_init.argtypes = [vp, i64, vp]
+        L.bfpq_tie_workspace_elems.argtypes = [i64, i32]
+        L.bfpq_tie_workspace_elems.restype = i64
         L.bfpq_select_hist.argtypes = [vp, i64, i32, i32, vp, vp, vp]
-        L.bfpq_select_scan.argtypes = [i32, i32, vp, vp, vp]
+        L.bfpq_select_scan.argtypes = [i32, i32, vp, vp, i64, vp]
         L.bfpq_tie_count.argtypes = [vp, i64, i32, vp, vp, vp]
         L.bfpq_threshold_apply.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
+        L.bfpq_quantize_threshold.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, dbl, i32, u64, vp, vp, vp, vp, vp, vp]
         for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
-                     "bfpq_select_passes", "bfpq_select_init", "bfpq_select_hist", "bfpq_select_scan", "bfpq_tie_count",
-                     "bfpq_threshold_apply"):
+                     "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan", "bfpq_tie_count",
+                     "bfpq_threshold_apply", "bfpq_quantize_threshold"):
             getattr(L, name).restype = i32
         _lib = L
         return _lib
 
 
-EXPORTED_SYMBOLS = ("bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host",
+EXPORTED_SYMBOLS = ("bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
-                    "bfpq_select_passes", "bfpq_select_init", "bfpq_select_hist", "bfpq_select_scan",
-                    "bfpq_tie_count", "bfpq_threshold_apply")
+                    "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan",
+                    "bfpq_tie_count", "bfpq_threshold_apply", "bfpq_quantize_threshold")
 
 
 def check(rc, what):
@@ -202,9 +203,17 @@ class SelectWorkspace:
     """Device scratch of the unstructured path (state + histogram + per-chunk tie counts)."""
 
     def __init__(self, device):
+        self.device = device
         self.state = torch.zeros(SELECT_STATE_BYTES // 8, dtype=torch.int64, device=device)
-        self.hist = torch.zeros(SELECT_HIST_BINS, dtype=torch.int32, device=device)
-        self.tie_counts = torch.zeros(TIE_CHUNKS, dtype=torch.int32, device=device)
+        self.hist = torch.zeros(SELECT_HIST_BINS, dtype=torch.int32, device=device)     # every scan re-zeroes it
+        self.tie = torch.zeros(1024, dtype=torch.int32, device=device)
+
+    def tie_ws(self, numel, dtype_code):
+        """one entry per 64-lane-item tile (tie prefix); grows with the largest tensor seen"""
+        need = int(load_library().bfpq_tie_workspace_elems(int(numel), int(dtype_code)))
+        if self.tie.numel() < need:
+            self.tie = torch.zeros(need, dtype=torch.int32, device=self.device)
+        return self.tie
 
     def read_state(self):
         """host copy of bfpq_select_state (synchronises; for tests / diagnostics only)"""
@@ -223,13 +232,51 @@ def select_threshold(t, k, ws, allreduce=None):
     code = DTYPE_CODE[src.dtype]
     with torch.cuda.device(src.device):
         st = _stream(src)
-        check(L.bfpq_select_init(_ptr(ws.state), int(k), st), "bfpq_select_init")
-        for p in range(L.bfpq_select_passes(code)):
-            ws.hist.zero_()
+        for p in range(L.bfpq_select_passes(code)):       # ws.hist is zero on entry; every scan leaves it zeroed again
             check(L.bfpq_select_hist(_ptr(src), src.numel(), code, p, _ptr(ws.state), _ptr(ws.hist), st), "bfpq_select_hist")
             if allreduce is not None:
                 allreduce(ws.hist)
-            check(L.bfpq_select_scan(code, p, _ptr(ws.state), _ptr(ws.hist), st), "bfpq_select_scan")
+            check(L.bfpq_select_scan(code, p, _ptr(ws.state), _ptr(ws.hist), int(k), st), "bfpq_select_scan")
+
+
+def _tie_ranks(src, code, ws, exchange_ties, st):
+    """tie counts per tile (skipped on the device when ranks are not needed) and, multi-GPU, the number
+    of ties held by lower ranks"""
+    L = load_library()
+    tie = ws.tie_ws(src.numel(), code)
+    check(L.bfpq_tie_count(_ptr(src), src.numel(), code, _ptr(ws.state), _ptr(tie), st), "bfpq_tie_count")
+    if exchange_ties is not None:
+        return exchange_ties(ws.state[6:7])              # bfpq_select_state.reserved[0]: this rank's tie total
+    return None
+
+
+def quantize_threshold(t, ws, block_size, mant_bits, epsilon, want_deq=True, code_bits=0, want_exp=False,
+                       stoch_seed=0, out=None, exchange_ties=None):
+    """S-first unstructured: prune with the threshold held in ws.state and HBFP-quantize, one pass
+    (bfpq_quantize_threshold).  Returns (deq | None, codes | None, exps | None) like quantize_nm."""
+    require_device_tensor(t)
+    L = load_library()
+    src = t.contiguous()
+    rows, cols = rows_cols(src)
+    code = DTYPE_CODE[src.dtype]
+    dev = src.device
+    with torch.cuda.device(dev):
+        st = _stream(src)
+        tie_base = _tie_ranks(src, code, ws, exchange_ties, st)
+        deq = (out if out is not None else torch.empty_like(src)) if want_deq else None
+        codes = exps = None
+        if code_bits:
+            shape = (rows, (cols + 1) // 2) if code_bits == 4 else (rows, cols)
+            codes = torch.empty(shape, dtype={4: torch.uint8, 8: torch.int8, 16: torch.int16}[code_bits], device=dev)
+        if want_exp:
+            exps = torch.empty((rows, (cols + block_size - 1) // block_size), dtype=torch.int8, device=dev)
+        fused = L.bfpq_is_fused(rows, cols, code, int(block_size), 0, 0)
+        scratch = torch.empty_like(src) if (not fused and deq is None) else None
+        check(L.bfpq_quantize_threshold(_ptr(src), _ptr(deq), _ptr(codes), _ptr(exps), rows, cols, code, int(block_size),
+                                        int(mant_bits), float(epsilon), int(code_bits), int(stoch_seed),
+                                        _ptr(exp_window_dev(src.dtype, dev)), _ptr(ws.state), _ptr(ws.tie),
+                                        _ptr(tie_base), _ptr(scratch), st), "bfpq_quantize_threshold")
+    return deq, codes, exps
 
 
 def threshold_apply(t, ws, out=None, tie_base=None, exchange_ties=None):
@@ -243,9 +290,9 @@ def threshold_apply(t, ws, out=None, tie_base=None, exchange_ties=None):
     with torch.cuda.device(src.device):
         st = _stream(src)
         dst = out if out is not None else torch.empty_like(src)
-        check(L.bfpq_tie_count(_ptr(src), src.numel(), code, _ptr(ws.state), _ptr(ws.tie_counts), st), "bfpq_tie_count")
-        if exchange_ties is not None:
-            tie_base = exchange_ties(ws.tie_counts.sum(dtype=torch.int64).reshape(1))
-        check(L.bfpq_threshold_apply(_ptr(src), _ptr(dst), src.numel(), code, _ptr(ws.state), _ptr(ws.tie_counts),
+        tb = _tie_ranks(src, code, ws, exchange_ties, st)
+        if tb is not None:
+            tie_base = tb
+        check(L.bfpq_threshold_apply(_ptr(src), _ptr(dst), src.numel(), code, _ptr(ws.state), _ptr(ws.tie),
                                      _ptr(tie_base), st), "bfpq_threshold_apply")
     return dst

@@ -255,6 +255,30 @@ def test_oracle_parity_cfg4_unstructured_13b():
     assert_bits_equal(bits(yq), bits(want), torch.bfloat16, "cfg4 s then q")
 
 
+@pytest.mark.parametrize("shape,dname", [((512, 1024), "bf16"), ((333, 777), "f16"), ((257, 129), "f32"), ((64, 4096), "f32"), ((1, 5), "bf16")])
+def test_unstructured_fused_and_fallback(shape, dname):
+    """sparsify->quantize with a global threshold: the single-pass kernel on flat shapes, the two-launch
+    fallback on ragged ones (numel not a multiple of the vector width, cols not a multiple of the block)"""
+    dt = DT[dname]
+    xc = synth(shape[0], shape[1], dt, seed=77)
+    x = xc.to(DEV)
+    for frac in (0.5, 0.37, 0.99):
+        ys = bfp_ops._unstructured_sparsity(x, 'cuda', frac)
+        _tie_class_check(xc, ys, frac, dt, f"unstructured {shape} {dname} {frac}")
+        for m, blk in ((3, 64), (7, 16)):
+            c = cfg(mant_bits=m, block_size=blk, w_sparsity=True, sparsity_mode='unstructured', sparsity_frac=frac, first='s')
+            got = bfp_ops.float_to_bfp_blocked(x, **c, identifier='w')
+            want = O.no_sparsity_float_to_bfp(ys.cpu(), blk, m)
+            assert_bits_equal(bits(got), bits(want), dt, f"fused unstructured {shape} {dname} {frac} m{m} b{blk}")
+    # tie-heavy integer-generated input (thousands of elements equal to the threshold)
+    xb = from_bits(int_bits_tensor(shape, dname, 5), dt).view(shape)
+    ys = bfp_ops._unstructured_sparsity(xb.to(DEV), 'cuda', 0.5)
+    _tie_class_check(xb, ys, 0.5, dt, f"tie-heavy {shape} {dname}")
+    c = cfg(w_sparsity=True, sparsity_mode='unstructured', first='s')
+    got = bfp_ops.float_to_bfp_blocked(xb.to(DEV), **c, identifier='w')
+    assert_bits_equal(bits(got), bits(O.no_sparsity_float_to_bfp(ys.cpu(), 64, 3)), dt, f"tie-heavy fused {shape} {dname}")
+
+
 # ---- packed output -----------------------------------------------------------------------------
 @pytest.mark.parametrize("dname,m,blk,code_bits", [("bf16", 3, 64, 4), ("f16", 3, 32, 4), ("f32", 7, 16, 8), ("bf16", 7, 64, 8), ("f32", 15, 32, 16)])
 def test_packed_roundtrip(dname, m, blk, code_bits):
