@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--allgather", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real multi-GPU; gloo only to rehearse N>1 on one GPU")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -92,11 +94,16 @@ def main():
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the engine has no CPU path)")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import quantization_sparsity_interplay_amd as pkg
     from quantization_sparsity_interplay_amd import native
@@ -172,7 +179,7 @@ def main():
     wall = t1 - t0
     ev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
+        t = torch.tensor([wall], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from .. import native
 
 __all__ = ["rounding_modes", "round_tensor", "get_exponent", "float_to_bfp_blocked", "float_to_bfp_packed",
-           "sparsify", "unpack_bfp_args", "F_linear_bfp", "F_matmul_bfp", "BFPLinear", "BFPConv2d"]
+           "sparsify", "unpack_bfp_args", "F_linear_bfp", "F_matmul_bfp", "BFPLinear", "BFPConv2d", "WeightCache"]
 
 
 class rounding_modes:
@@ -226,16 +226,57 @@ def _get_op_name(name, epsilon, mant_bits, rounding_mode, **kwargs):
     return '%s_BFP_%s_%d' % (name, rounding_mode, mant_bits)
 
 
+class WeightCache:
+    """Opt-in cache of the quantized (and sparsified) weight operand, keyed on the parameter's identity,
+    in-place version counter, dtype and device.  The reference re-runs the whole path on the unchanged weight in
+    every forward (bfp_ops.py:151-166, 7 Linear layers per LLaMA block); with the cache an inference loop
+    quantizes each weight once.  Off by default (reference semantics); stochastic rounding is never cached."""
+
+    def __init__(self):
+        self.key = None
+        self.value = None
+        self.hits = 0
+        self.misses = 0
+
+    def lookup(self, w, bfp_args):
+        if bfp_args.get('rounding_mode') != rounding_modes.DETERM:
+            return None
+        key = (w.data_ptr(), w._version, w.dtype, w.device, tuple(w.shape))
+        if self.key == key:
+            self.hits += 1
+            return self.value
+        return None
+
+    def store(self, w, wq):
+        self.key = (w.data_ptr(), w._version, w.dtype, w.device, tuple(w.shape))
+        self.value = wq.detach()
+        self.misses += 1
+
+
 class _OperandQuantizer(torch.autograd.Function):
     """forward: (x, w) -> (Q_in(x), Q_w(w)); backward: straight-through (reference NewOpIn, bfp_ops.py:163-170)"""
 
     @staticmethod
-    def forward(ctx, x, w, transpose, bfp_args):
-        return MxM_pre_processing(x, w, transpose, **bfp_args)
+    def forward(ctx, x, w, transpose, bfp_args, cache):
+        if cache is None:
+            return MxM_pre_processing(x, w, transpose, **bfp_args)
+        xq = float_to_bfp_blocked(x, **bfp_args, identifier='in')
+        wq = cache.lookup(w, bfp_args)
+        if wq is None:
+            wq = _quantize_weight_operand(w, transpose, bfp_args)
+            cache.store(w, wq)
+        return xq, wq
 
     @staticmethod
     def backward(ctx, grad_x, grad_w):
-        return grad_x, grad_w, None, None
+        return grad_x, grad_w, None, None, None
+
+
+def _quantize_weight_operand(w, transpose, bfp_args):
+    """the second operand of MxM_pre_processing alone"""
+    if transpose == True:  # noqa: E712
+        return float_to_bfp_blocked(w.transpose(-1, -2), **bfp_args, identifier='w').transpose(-1, -2)
+    return float_to_bfp_blocked(w, **bfp_args, identifier='w')
 
 
 class _GradQuantizer(torch.autograd.Function):
@@ -251,20 +292,21 @@ class _GradQuantizer(torch.autograd.Function):
         return float_to_bfp_blocked(grad_out, **ctx.bfp_args, identifier='grad'), None
 
 
-def _gen_bfp_op(op, name, bfp_args, transpose=False):
+def _gen_bfp_op(op, name, bfp_args, transpose=False, cache=None):
     """reference: bfp_ops.py:160-192 -- wraps `op(x, w, ...)` so that both operands are BFP-quantized
-    (and sparsified) on the way in and the output gradient on the way back."""
+    (and sparsified) on the way in and the output gradient on the way back.  cache: optional WeightCache."""
     def bfp_op(x, w, *args, **kwargs):
-        xq, wq = _OperandQuantizer.apply(x, w, transpose, bfp_args)
+        xq, wq = _OperandQuantizer.apply(x, w, transpose, bfp_args, cache)
         return _GradQuantizer.apply(op(xq, wq, *args, **kwargs), bfp_args)
 
     bfp_op.__name__ = _get_op_name(name, **bfp_args)
+    bfp_op.weight_cache = cache
     return bfp_op
 
 
-def _get_bfp_op(op, name, bfp_args, transpose=False):
+def _get_bfp_op(op, name, bfp_args, transpose=False, cache=None):
     """reference: bfp_ops.py:194-200 (its cache dict is a local, so there too every layer gets its own op)"""
-    return _gen_bfp_op(op, name, bfp_args, transpose)
+    return _gen_bfp_op(op, name, bfp_args, transpose, cache)
 
 
 _BFP_ARG_DEFAULTS = dict(num_format='fp32', sparsity_num_format='fp32', rounding_mode='stoc', epsilon=1e-8,
@@ -302,6 +344,16 @@ class _BFPModule:
     def _bfp_finish(self):
         self.num_format = self.bfp_args['num_format']
         return _get_bfp_op(self._functional, self._op_name, self.bfp_args)
+
+    def enable_weight_cache(self, enabled=True):
+        """opt in to (or out of) caching the quantized weight across forwards; see WeightCache"""
+        cache = WeightCache() if enabled else None
+        op = _get_bfp_op(self._functional, self._op_name, self.bfp_args, cache=cache)
+        if hasattr(self, 'linear_op'):
+            self.linear_op = op
+        else:
+            self.conv_op = op
+        return self
 
     def _bfp_forward(self, bfp_op, *operands):
         if self.num_format == 'fp32':

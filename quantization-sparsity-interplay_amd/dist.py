@@ -113,3 +113,38 @@ def float_to_bfp_packed_sharded(local, rows_total, mant_bits, block_size, group=
     if gather:
         return all_gather_rows(codes, rows_total, group), all_gather_rows(exps, rows_total, group)
     return codes, exps
+
+
+def gather_overlapped(local, rows_total, compute, chunks=4, group=None):
+    """out = all-gather over ranks of compute(local), with the gather of row-chunk i overlapped with the
+    compute of chunk i+1: the slab is cut into `chunks` row pieces; each piece is computed on the current
+    stream and all-gathered on a side stream as soon as it is done (an event orders the two), straight into
+    its rows of the full result.  Needs an even row split (rows_total % world == 0).
+    compute(piece) -> tensor with the same number of rows (quantize / N:M: rows are independent)."""
+    world = dist.get_world_size(group)
+    per = rows_total // world
+    assert per * world == rows_total and local.shape[0] == per, "gather_overlapped needs an even row split"
+    bounds = [per * i // chunks for i in range(chunks + 1)]
+    on_gpu = local.device.type == "cuda"
+    out = None
+    side = torch.cuda.Stream(local.device) if on_gpu else None
+    for i in range(chunks):
+        lo, hi = bounds[i], bounds[i + 1]
+        if hi == lo:
+            continue
+        piece = compute(local[lo:hi]).contiguous()
+        if out is None:
+            out = torch.empty((rows_total,) + tuple(piece.shape[1:]), dtype=piece.dtype, device=piece.device)
+        views = [out[r * per + lo: r * per + hi] for r in range(world)]       # contiguous row slices of the result
+        if on_gpu:
+            done = torch.cuda.Event()
+            done.record()
+            with torch.cuda.stream(side):
+                side.wait_event(done)
+                dist.all_gather(views, piece, group=group)
+                piece.record_stream(side)
+        else:
+            dist.all_gather(views, piece, group=group)
+    if on_gpu:
+        torch.cuda.current_stream(local.device).wait_stream(side)
+    return out

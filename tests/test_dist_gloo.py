@@ -119,6 +119,12 @@ def _worker(rank, world, port, tmpdir):
                     assert int((allp == 0).sum()) == int((ref == 0).sum())
                     assert torch.equal(allp.float().abs().min(dim=1)[0] >= 0, torch.ones(rows, dtype=torch.bool))
             results[rows] = True
+        # chunked gather (overlap path; on CPU the chunks simply run in order)
+        full = (torch.randn(64, 256, generator=g) * 0.02).to(torch.bfloat16)
+        c = _cfg()
+        got = qd.gather_overlapped(qd.shard_rows(full, world, rank), 64,
+                                   lambda p: O.float_to_bfp_blocked(p, **c, identifier='w'), chunks=3)
+        assert torch.equal(got.view(torch.int16), O.float_to_bfp_blocked(full, **c, identifier='w').view(torch.int16))
         # ragged all_gather of a different dtype (packed codes / exponents travel as uint8 / int8)
         codes = torch.arange(37 * 8, dtype=torch.uint8).view(37, 8)
         got = qd.all_gather_rows(qd.shard_rows(codes, world, rank), 37)

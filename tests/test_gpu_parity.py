@@ -414,3 +414,26 @@ def test_graph_capture_and_side_stream():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, want)
+
+
+def test_weight_cache_opt_in():
+    """§8f next #1: cached quantized weight == re-quantized weight; invalidated by an in-place update"""
+    kw = cfg(mant_bits=7, block_size=32, N=2, M=4, w_sparsity=True)
+    lin = bfp_ops.BFPLinear(64, 128, True, **dict(kw)).to(DEV)
+    ref = bfp_ops.BFPLinear(64, 128, True, **dict(kw)).to(DEV)
+    ref.load_state_dict(lin.state_dict())
+    lin.enable_weight_cache()
+    x = synth(10, 64, torch.float32, 1.0).to(DEV).requires_grad_(True)
+    x2 = x.detach().clone().requires_grad_(True)
+    for it in range(3):
+        y, yr = lin(x), ref(x2)
+        assert torch.equal(y, yr)
+    cache = lin.linear_op.weight_cache
+    assert cache.misses == 1 and cache.hits == 2
+    y.sum().backward(); yr.sum().backward()
+    assert torch.equal(x.grad, x2.grad) and torch.equal(lin.weight.grad, ref.weight.grad)     # straight-through to w
+    with torch.no_grad():
+        lin.weight.add_(0.01); ref.weight.add_(0.01)                                           # bumps weight._version
+    assert torch.equal(lin(x), ref(x2)) and cache.misses == 2
+    lin.enable_weight_cache(False)
+    assert lin.linear_op.weight_cache is None and torch.equal(lin(x), ref(x2))
