@@ -135,6 +135,17 @@ int bfpq_quantize_threshold(const void* in_dev, void* out_deq_dev, void* out_cod
                             const void* state_dev, const uint32_t* tie_ws_dev, const int64_t* tie_base_dev,
                             void* scratch_dev, void* stream);
 
+/* ---- 'int' per-channel format (replaces _quantize's 'int' branch, bfp_ops.py:111-120, i.e.
+ * int_ops.Quantizer.configure/find_params/quantize with the defaults perchannel=True, sym=True) -------
+ * The tensor is viewed as [outer, C, inner] with the channel in the middle (int_ops.py:38-50):
+ * weight: outer = 1, C = shape[0], inner = rest; 2-D/3-D activation: outer = rows, C = last dim,
+ * inner = 1; 4-D activation: outer = N, C = shape[1], inner = H*W.  maxq = 2^bits - 1.
+ * out_dev is fp32 for every input dtype (as in the reference).  ws_dev: bfpq_int_workspace_elems(C)
+ * uint32, needed (any content) unless outer == 1. */
+int64_t bfpq_int_workspace_elems(int64_t C);
+int bfpq_int_quantize(const void* in_dev, float* out_dev, int64_t outer, int64_t C, int64_t inner, int dtype, int bits,
+                      uint32_t* ws_dev, void* stream);
+
 /* layout of state_dev as read back by a host that wants tau / counts (all little-endian) */
 typedef struct bfpq_select_state {
     uint32_t prefix;      /* magnitude bits decided so far (high digits)                         */

@@ -417,4 +417,46 @@ int oracle_float_to_bfp_blocked(const void* in, void* out, int64_t rows, int64_t
     return rc;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * 'int' format: _quantize's branch bfp_ops.py:111-120 -> int_ops.Quantizer with configure() defaults
+ * (perchannel=True, sym=True, mse=False, grouprows=1; int_ops.py:18-31), find_params (:33-115) and
+ * quantize (:6-8, :117-120).  The tensor is viewed as [outer, C, inner] with the channel in the middle:
+ *   weight (identifier 'w'):  x.flatten(1)            -> outer = 1, C = shape[0], inner = rest   (:39-42)
+ *   2-D / 3-D activation:     reshape(-1, C).t()      -> outer = rows, C = last dim, inner = 1   (:47-50)
+ *   4-D activation:           permute(1,0,2,3)        -> outer = N, C = shape[1], inner = H*W    (:44-46)
+ * min/max are taken against an fp32 zero tensor (:54-56), which promotes everything after it to fp32:
+ * the result is an fp32 tensor whatever the input dtype.
+ * ---------------------------------------------------------------------------------------- */
+int oracle_int_quantize(const void* in, float* out, int64_t outer, int64_t C, int64_t inner, int dtype, int bits)
+{
+    if (outer < 0 || C < 0 || inner < 0 || dtype < 0 || dtype > 2 || bits < 0 || bits > 30) return -1;
+    const float maxq = (float)((1u << bits) - 1u);                       /* 2**bits - 1            :24 */
+    const float zero = (maxq + 1.0f) / 2.0f;                             /* (maxq + 1) / 2         :69 */
+    #pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < C; c++) {
+        float xmin = 0.0f, xmax = 0.0f;                                  /* minimum / maximum with zeros :55-56 */
+        int nan = 0;
+        for (int64_t o = 0; o < outer; o++)
+            for (int64_t i = 0; i < inner; i++) {
+                const float v = ld(in, (o * C + c) * inner + i, dtype);
+                if (v != v) nan = 1;
+                else { if (v < xmin) xmin = v; if (v > xmax) xmax = v; }
+            }
+        if (nan) { xmin = NAN; xmax = NAN; }                             /* torch min/max propagate NaN */
+        xmax = t_max(fabsf(xmin), xmax);                                 /* sym :59 */
+        if (xmin < 0) xmin = -xmax;                                      /* :60-62 */
+        if (xmin == 0 && xmax == 0) { xmin = -1.0f; xmax = 1.0f; }       /* :63-65 */
+        const float scale = (xmax - xmin) / maxq;                        /* :67 */
+        for (int64_t o = 0; o < outer; o++)
+            for (int64_t i = 0; i < inner; i++) {
+                const int64_t idx = (o * C + c) * inner + i;
+                const float x = ld(in, idx, dtype);
+                float q = rintf(x / scale) + zero;                       /* round(x / scale) + zero :7 */
+                q = t_min(t_max(q, 0.0f), maxq);                         /* clamp(., 0, maxq)       :7 */
+                out[idx] = scale * (q - zero);                           /* scale * (q - zero)      :8 */
+            }
+    }
+    return 0;
+}
+
 int oracle_version(void) { return 1; }

@@ -42,6 +42,8 @@ def lib():
         L.oracle_unstructured_sparsify.argtypes = [vp, vp, i64, i32, dbl, vp, vp]
         L.oracle_float_to_bfp_blocked.argtypes = [vp, vp, i64, i64, i32, i32, i32, i32, dbl, i32, i32, i32, dbl, i32]
         L.oracle_topk_smallest_mask.argtypes = [vp, i64, i64, vp]
+        L.oracle_int_quantize.argtypes = [vp, vp, i64, i64, i64, i32, i32]
+        L.oracle_int_quantize.restype = ctypes.c_int
         for f in (L.oracle_bfp_quantize, L.oracle_nm_sparsify, L.oracle_unstructured_sparsify,
                   L.oracle_float_to_bfp_blocked, L.oracle_topk_smallest_mask, L.oracle_version):
             f.restype = ctypes.c_int
@@ -102,6 +104,31 @@ def topk_smallest_mask(absvals, k):
     return m
 
 
+def int_channel_view(shape, weight):
+    """(outer, C, inner) of int_ops.Quantizer.find_params' per-channel view (int_ops.py:38-50)"""
+    shape = tuple(shape)
+    n = 1
+    for d in shape:
+        n *= d
+    if weight:
+        return 1, shape[0], n // max(shape[0], 1)
+    if len(shape) == 4:
+        return shape[0], shape[1], shape[2] * shape[3]
+    if len(shape) in (2, 3):
+        return n // max(shape[-1], 1), shape[-1], 1
+    raise ValueError("int_ops.Quantizer handles 2-D, 3-D and 4-D activations only")
+
+
+def int_quantize(t, bits, weight):
+    """reference: _quantize 'int' branch, bfp_ops.py:111-120 (returns fp32 like the reference)"""
+    t = t.contiguous()
+    assert t.device.type == "cpu" and t.dtype in _DT
+    outer, C, inner = int_channel_view(t.shape, weight)
+    out = torch.empty(t.shape, dtype=torch.float32)
+    _check(lib().oracle_int_quantize(t.data_ptr(), out.data_ptr(), outer, C, inner, _DT[t.dtype], int(bits)), "int_quantize")
+    return out
+
+
 def float_to_bfp_blocked(t, mant_bits, epsilon, rounding_mode, device, block_size, num_format,
                          weight_mant_bits, in_sparsity, w_sparsity, grad_sparsity, sparsity_frac,
                          N, M, sparsity_num_format, first, sparsity_mode, identifier='',
@@ -123,6 +150,17 @@ def float_to_bfp_blocked(t, mant_bits, epsilon, rounding_mode, device, block_siz
             raise ValueError(f'Unknown sparsity mode: {sparsity_mode} given as argument')
     else:
         smode = 0
+    if sparsity_num_format == 'int':
+        # composition done here in Python: the quantizer changes the dtype to fp32 (reference quirk)
+        bits = weight_mant_bits if sgd_update else mant_bits
+
+        def S(x):
+            if not sparsity:
+                return x
+            return structured_N_M_sparsity(x, N, M).view(x.shape) if smode == 1 else unstructured_sparsity(x, sparsity_frac).view(x.shape)
+        if first == 's':
+            return int_quantize(S(t), bits, identifier == 'w')
+        return S(int_quantize(t, bits, identifier == 'w'))
     if sparsity_num_format == 'fp32':
         q = 0
     elif sparsity_num_format == 'bfp':

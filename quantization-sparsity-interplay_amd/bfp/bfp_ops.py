@@ -9,7 +9,6 @@ Differences from the reference, all documented in DESIGN.md:
     (torch.manual_seed controls it); the reference's torch.rand stream is not reproduced.
   * _unstructured_sparsity: which of the elements EQUAL to the threshold are pruned is "lowest flat
     index first"; the reference's choice is an artefact of a sequential introselect.
-  * sparsity_num_format == 'int' (SparseGPT per-channel quantizer, bfp_ops.py:111-120) is not built.
 """
 import torch
 import torch.nn.functional as F
@@ -132,8 +131,12 @@ def _quantize(t, num_format, block_size, mant_bits, weight_mant_bits, sgd_update
             mant_bits = weight_mant_bits
         return _no_sparsity_float_to_bfp(t, block_size, mant_bits, epsilon, rounding_mode, device)
     elif num_format == 'int':
-        raise NotImplementedError("sparsity_num_format 'int' (SparseGPT per-channel quantizer, reference "
-                                  "bfp_ops.py:111-120 / int_ops.py) is not built in this engine yet")
+        # per-channel symmetric integer grid (int_ops.Quantizer with its defaults); fp32 result as in the reference
+        if sgd_update:
+            mant_bits = weight_mant_bits
+        quant_t = native.int_quantize(t, mant_bits, identifier == 'w')
+        assert (t.shape == quant_t.shape)
+        return quant_t
     else:
         raise ValueError(f'Unknown quantization format: {num_format} given as argument')
 

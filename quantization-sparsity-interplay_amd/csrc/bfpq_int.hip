@@ -1,0 +1,219 @@
+// bfpq_int.hip -- the 'int' per-channel format of the reference's _quantize (bfp_ops.py:111-120):
+// int_ops.Quantizer with configure() defaults (perchannel, symmetric; int_ops.py:18-31),
+// find_params (:33-115) and quantize (:6-8).  Result is fp32 whatever the input dtype (the reference
+// takes min/max against an fp32 zero tensor, which promotes everything downstream).
+//
+// The tensor is viewed as [outer, C, inner], the channel in the middle:
+//   weight:            outer = 1,    C = shape[0],  inner = rest           -> k_int_rows  (one pass kernel:
+//                                                                             a wave or a workgroup owns a channel,
+//                                                                             reduces min/max, then quantizes it;
+//                                                                             the second read of the row is L2-served)
+//   2-D/3-D activation outer = rows, C = last dim,  inner = 1              -> k_int_cols_minmax (+ atomics on
+//                                                                             order-preserving integer keys:
+//                                                                             deterministic) / k_int_cols_quant
+//   4-D activation     outer = N,    C = shape[1],  inner = H*W            -> k_int_seg_minmax / k_int_seg_quant
+// All fp32 arithmetic is single IEEE operations in the reference's order (x / scale is a true division),
+// compiled with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bfpq.h"
+#include "bfpq_common.h"
+
+using namespace bfpq;
+
+namespace {
+
+constexpr int kT = 256;
+
+// order-preserving map float bits -> uint32 (so integer atomicMin/Max order floats; NaNs sort outermost)
+__device__ __forceinline__ uint32_t f_key(float f) { const uint32_t u = f2u(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float key_f(uint32_t k) { return u2f((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+// find_params for one channel (int_ops.py:54-67): returns scale; min/max are the raw channel extrema
+__device__ __forceinline__ float int_scale(float xmin, float xmax, float maxq)
+{
+    xmin = t_min(xmin, 0.0f);                              // torch.minimum(x.min(1)[0], zeros)   :55
+    xmax = t_max(xmax, 0.0f);                              // torch.maximum(x.max(1)[0], zeros)   :56
+    xmax = t_max(fabsf(xmin), xmax);                       // sym                                  :59
+    if (xmin < 0.0f) xmin = -xmax;                         //                                      :60-62
+    if (xmin == 0.0f && xmax == 0.0f) { xmin = -1.0f; xmax = 1.0f; }   //                           :63-65
+    return (xmax - xmin) / maxq;                           //                                      :67
+}
+
+__device__ __forceinline__ float int_q(float x, float scale, float zero, float maxq)
+{
+    float q = rintf(x / scale) + zero;                     // round(x / scale) + zero              :7
+    q = t_min(t_max(q, 0.0f), maxq);                       // clamp(., 0, maxq)
+    return scale * (q - zero);                             //                                      :8
+}
+
+template <int DT> __device__ __forceinline__ float ldf(const void* in, int64_t i)
+{
+    using raw_t = typename Traits<DT>::raw_t;
+    return raw_to_f32<DT>((uint32_t)reinterpret_cast<const raw_t*>(in)[i]);
+}
+
+__device__ __forceinline__ void wave_minmax(float& mn, float& mx, bool& nan)
+{
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    }
+    nan = __any(nan);
+}
+
+// weight path: G threads (64 = one wave, or the whole 256-thread workgroup) own one channel of `inner`
+// contiguous elements
+template <int DT, int G>
+__global__ void __launch_bounds__(kT) k_int_rows(const void* in, float* out, int64_t C, int64_t inner, float maxq, float zero)
+{
+    __shared__ float s_mn[kT / 64], s_mx[kT / 64];
+    __shared__ int s_nan[kT / 64];
+    constexpr int PER_WG = kT / G;
+    const int sub = threadIdx.x / G, lig = threadIdx.x % G;
+    for (int64_t c0 = (int64_t)blockIdx.x * PER_WG; c0 < C; c0 += (int64_t)gridDim.x * PER_WG) {
+        const int64_t c = c0 + sub;
+        const bool live = c < C;
+        const int64_t base = (live ? c : 0) * inner;
+        float mn = 0.0f, mx = 0.0f;
+        bool nan = false;
+        if (live)
+            for (int64_t i = lig; i < inner; i += G) {
+                const float v = ldf<DT>(in, base + i);
+                nan |= v != v;
+                mn = fminf(mn, v); mx = fmaxf(mx, v);          // fminf/fmaxf skip NaN; tracked separately
+            }
+        wave_minmax(mn, mx, nan);
+        if constexpr (G > 64) {
+            const int w = threadIdx.x >> 6;
+            if ((threadIdx.x & 63) == 0) { s_mn[w] = mn; s_mx[w] = mx; s_nan[w] = nan; }
+            __syncthreads();
+            for (int i = 0; i < kT / 64; i++) { mn = fminf(mn, s_mn[i]); mx = fmaxf(mx, s_mx[i]); nan |= s_nan[i] != 0; }
+            __syncthreads();
+        }
+        if (nan) { mn = u2f(0x7fc00000u); mx = mn; }           // torch min/max propagate NaN
+        const float scale = int_scale(mn, mx, maxq);
+        if (live)
+            for (int64_t i = lig; i < inner; i += G) out[base + i] = int_q(ldf<DT>(in, base + i), scale, zero, maxq);
+    }
+}
+
+// activation path (inner == 1): thread owns one column of a chunk of rows
+template <int DT>
+__global__ void __launch_bounds__(kT) k_int_cols_minmax(const void* in, int64_t outer, int64_t C, int64_t rows_per_chunk, uint32_t* ws)
+{
+    const int64_t col = (int64_t)blockIdx.x * kT + threadIdx.x;
+    if (col >= C) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < outer ? r0 + rows_per_chunk : outer;
+    float mn = 0.0f, mx = 0.0f;
+    bool nan = false;
+    for (int64_t r = r0; r < r1; r++) {
+        const float v = ldf<DT>(in, r * C + col);
+        nan |= v != v;
+        mn = fminf(mn, v); mx = fmaxf(mx, v);
+    }
+    if (nan) { mn = u2f(0xffc00000u); mx = u2f(0x7fc00000u); }     // keys: -NaN smallest, +NaN largest
+    atomicMin(&ws[col], f_key(mn));
+    atomicMax(&ws[C + col], f_key(mx));
+}
+
+template <int DT>
+__global__ void __launch_bounds__(kT) k_int_cols_quant(const void* in, float* out, int64_t outer, int64_t C, int64_t rows_per_chunk,
+                                                       const uint32_t* ws, float maxq, float zero)
+{
+    const int64_t col = (int64_t)blockIdx.x * kT + threadIdx.x;
+    if (col >= C) return;
+    const float scale = int_scale(key_f(ws[col]), key_f(ws[C + col]), maxq);
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < outer ? r0 + rows_per_chunk : outer;
+    for (int64_t r = r0; r < r1; r++) out[r * C + col] = int_q(ldf<DT>(in, r * C + col), scale, zero, maxq);
+}
+
+// 4-D activation path: one wave per (outer, channel) segment of `inner` contiguous elements
+template <int DT>
+__global__ void __launch_bounds__(kT) k_int_seg_minmax(const void* in, int64_t outer, int64_t C, int64_t inner, uint32_t* ws)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t nseg = outer * C;
+    for (int64_t seg = ((int64_t)blockIdx.x * kT + threadIdx.x) >> 6; seg < nseg; seg += (int64_t)gridDim.x * (kT / 64)) {
+        float mn = 0.0f, mx = 0.0f;
+        bool nan = false;
+        for (int64_t i = lane; i < inner; i += 64) {
+            const float v = ldf<DT>(in, seg * inner + i);
+            nan |= v != v;
+            mn = fminf(mn, v); mx = fmaxf(mx, v);
+        }
+        wave_minmax(mn, mx, nan);
+        if (nan) { mn = u2f(0xffc00000u); mx = u2f(0x7fc00000u); }
+        if (lane == 0) { atomicMin(&ws[seg % C], f_key(mn)); atomicMax(&ws[C + seg % C], f_key(mx)); }
+    }
+}
+
+template <int DT>
+__global__ void __launch_bounds__(kT) k_int_seg_quant(const void* in, float* out, int64_t outer, int64_t C, int64_t inner,
+                                                      const uint32_t* ws, float maxq, float zero)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t nseg = outer * C;
+    for (int64_t seg = ((int64_t)blockIdx.x * kT + threadIdx.x) >> 6; seg < nseg; seg += (int64_t)gridDim.x * (kT / 64)) {
+        const int64_t c = seg % C;
+        const float scale = int_scale(key_f(ws[c]), key_f(ws[C + c]), maxq);
+        for (int64_t i = lane; i < inner; i += 64) out[seg * inner + i] = int_q(ldf<DT>(in, seg * inner + i), scale, zero, maxq);
+    }
+}
+
+template <int DT>
+int run_int(const void* in, float* out, int64_t outer, int64_t C, int64_t inner, float maxq, float zero, uint32_t* ws, hipStream_t s)
+{
+    if (outer == 1) {
+        if (inner <= 16384) {
+            int64_t g = (C + 3) / 4;
+            hipLaunchKernelGGL((k_int_rows<DT, 64>), dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(kT), 0, s, in, out, C, inner, maxq, zero);
+        } else {
+            hipLaunchKernelGGL((k_int_rows<DT, 256>), dim3((unsigned)(C > 4096 ? 4096 : C)), dim3(kT), 0, s, in, out, C, inner, maxq, zero);
+        }
+        return (int)hipGetLastError();
+    }
+    if (!ws) return BFPQ_E_ARG;
+    hipError_t e = hipMemsetAsync(ws, 0xff, sizeof(uint32_t) * C, s);            // min keys start at the top
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(ws + C, 0x00, sizeof(uint32_t) * C, s);                   // max keys start at the bottom
+    if (e != hipSuccess) return (int)e;
+    if (inner == 1) {
+        int64_t chunks = (outer + 63) / 64;
+        if (chunks > 1024) chunks = 1024;
+        const int64_t rpc = (outer + chunks - 1) / chunks;
+        const dim3 grid((unsigned)((C + kT - 1) / kT), (unsigned)((outer + rpc - 1) / rpc));
+        hipLaunchKernelGGL((k_int_cols_minmax<DT>), grid, dim3(kT), 0, s, in, outer, C, rpc, ws);
+        hipLaunchKernelGGL((k_int_cols_quant<DT>), grid, dim3(kT), 0, s, in, out, outer, C, rpc, (const uint32_t*)ws, maxq, zero);
+    } else {
+        int64_t g = (outer * C + 3) / 4;
+        const dim3 grid((unsigned)(g > 4096 ? 4096 : g));
+        hipLaunchKernelGGL((k_int_seg_minmax<DT>), grid, dim3(kT), 0, s, in, outer, C, inner, ws);
+        hipLaunchKernelGGL((k_int_seg_quant<DT>), grid, dim3(kT), 0, s, in, out, outer, C, inner, (const uint32_t*)ws, maxq, zero);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t bfpq_int_workspace_elems(int64_t C) { return C < 0 ? BFPQ_E_ARG : 2 * C; }
+
+int bfpq_int_quantize(const void* in, float* out, int64_t outer, int64_t C, int64_t inner, int dtype, int bits,
+                      uint32_t* ws, void* stream)
+{
+    if (outer < 0 || C < 0 || inner < 0 || dtype < 0 || dtype > 2 || bits < 0 || bits > 30) return BFPQ_E_ARG;
+    if (outer * C * inner == 0) return 0;
+    if (!in || !out) return BFPQ_E_ARG;
+    const float maxq = (float)((1u << bits) - 1u);
+    const float zero = (maxq + 1.0f) / 2.0f;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == BFPQ_F32) return run_int<BFPQ_F32>(in, out, outer, C, inner, maxq, zero, ws, s);
+    if (dtype == BFPQ_F16) return run_int<BFPQ_F16>(in, out, outer, C, inner, maxq, zero, ws, s);
+    return run_int<BFPQ_BF16>(in, out, outer, C, inner, maxq, zero, ws, s);
+}
+
+}  // extern "C"

@@ -75,15 +75,18 @@ def load_library():
         L.bfpq_tie_count.argtypes = [vp, i64, i32, vp, vp, vp]
         L.bfpq_threshold_apply.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
         L.bfpq_quantize_threshold.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, dbl, i32, u64, vp, vp, vp, vp, vp, vp]
+        L.bfpq_int_workspace_elems.argtypes = [i64]
+        L.bfpq_int_workspace_elems.restype = i64
+        L.bfpq_int_quantize.argtypes = [vp, vp, i64, i64, i64, i32, i32, vp, vp]
         for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
                      "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan", "bfpq_tie_count",
-                     "bfpq_threshold_apply", "bfpq_quantize_threshold"):
+                     "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize"):
             getattr(L, name).restype = i32
         _lib = L
         return _lib
 
 
-EXPORTED_SYMBOLS = ("bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host",
+EXPORTED_SYMBOLS = ("bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
                     "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan",
                     "bfpq_tie_count", "bfpq_threshold_apply", "bfpq_quantize_threshold")
@@ -296,3 +299,36 @@ def threshold_apply(t, ws, out=None, tie_base=None, exchange_ties=None):
         check(L.bfpq_threshold_apply(_ptr(src), _ptr(dst), src.numel(), code, _ptr(ws.state), _ptr(ws.tie),
                                      _ptr(tie_base), st), "bfpq_threshold_apply")
     return dst
+
+
+def int_channel_view(shape, weight):
+    """(outer, C, inner): the per-channel view int_ops.Quantizer.find_params takes (reference int_ops.py:38-50)"""
+    shape = tuple(shape)
+    n = 1
+    for d in shape:
+        n *= d
+    if weight:
+        if len(shape) < 1:
+            raise ValueError("'int' format needs at least a 1-D weight")
+        return 1, shape[0], n // max(shape[0], 1)
+    if len(shape) == 4:
+        return shape[0], shape[1], shape[2] * shape[3]
+    if len(shape) in (2, 3):
+        return n // max(shape[-1], 1), shape[-1], 1
+    raise ValueError("'int' format handles 2-D, 3-D and 4-D activations (reference int_ops.py:43-50)")
+
+
+def int_quantize(t, bits, weight):
+    """per-channel symmetric integer fake-quantization (bfpq_int_quantize); fp32 result like the reference"""
+    require_device_tensor(t)
+    L = load_library()
+    src = t.contiguous()
+    outer, C, inner = int_channel_view(src.shape, weight)
+    out = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    if src.numel() == 0:
+        return out
+    with torch.cuda.device(src.device):
+        ws = torch.empty(2 * C, dtype=torch.int32, device=src.device) if outer != 1 else None
+        check(L.bfpq_int_quantize(_ptr(src), _ptr(out), outer, C, inner, DTYPE_CODE[src.dtype], int(bits), _ptr(ws), _stream(src)),
+              "bfpq_int_quantize")
+    return out

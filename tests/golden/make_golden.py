@@ -291,9 +291,43 @@ def main():
         g8[f"lin_gq_{dname}"] = bits(ops.float_to_bfp_blocked(gy, **kw, identifier='grad'))
     np.savez_compressed(os.path.join(HERE, "g8_nd_linear.npz"), **g8)
 
+    write_g9(ops)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("golden fixtures written, total bytes:", tot, "torch", torch.__version__)
 
 
+def write_g9(ops):
+    """G9: the 'int' per-channel format (bfp_ops.py:111-120 -> int_ops.Quantizer), weights and activations,
+    2-D / 3-D / 4-D, alone and composed with sparsity in both orders"""
+    g9 = {}
+    gen = torch.Generator().manual_seed(99)
+    shapes = {"w2": ((48, 200), 'w'), "a2": ((33, 96), 'in'), "a3": ((2, 7, 96), 'in'), "w4": ((8, 3, 5, 5), 'w'),
+              "a4": ((2, 6, 4, 4), 'in'), "g2": ((16, 64), 'grad')}
+    for name, (shape, ident) in shapes.items():
+        base = torch.randn(*shape, generator=gen) * 0.05
+        if name == "a2":
+            base[:, 3] = 0.0                     # an all-zero channel (xmin = xmax = 0 -> [-1, 1])
+            base[:, 5] = base[:, 5].abs()        # an all-positive channel (xmin stays 0)
+        for dname, dt in DT.items():
+            x = base.to(dt)
+            g9[f"in_{name}_{dname}"] = bits(x)
+            for nbits in (8, 4):
+                c = cfg(sparsity_num_format='int', mant_bits=nbits, block_size=32)
+                y = ops.float_to_bfp_blocked(x, **c, identifier=ident)
+                assert y.dtype == torch.float32
+                g9[f"out_{name}_{dname}_b{nbits}"] = bits(y)
+            if name in ("w2", "a3"):
+                flag = 'w_sparsity' if ident == 'w' else 'in_sparsity'
+                for first in ('s', 'q'):
+                    for mode, extra in (("structured", dict(N=2, M=4)), ("unstructured", dict(sparsity_frac=0.5))):
+                        c = cfg(sparsity_num_format='int', mant_bits=8, block_size=32, first=first, sparsity_mode=mode, **{flag: True}, **extra)
+                        y = ops.float_to_bfp_blocked(x, **c, identifier=ident)
+                        g9[f"comp_{name}_{dname}_{first}_{mode[:1]}"] = bits(y)
+    np.savez_compressed(os.path.join(HERE, "g9_int.npz"), **g9)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+        write_g9(load_ref())
+    else:
+        main()

@@ -437,3 +437,34 @@ def test_weight_cache_opt_in():
     assert torch.equal(lin(x), ref(x2)) and cache.misses == 2
     lin.enable_weight_cache(False)
     assert lin.linear_op.weight_cache is None and torch.equal(lin(x), ref(x2))
+
+
+def test_g9_int_format_golden():
+    """'int' per-channel format against the reference's own outputs (fp32 result for every dtype)"""
+    g = load("g9_int.npz")
+    shapes = {"w2": ((48, 200), 'w'), "a2": ((33, 96), 'in'), "a3": ((2, 7, 96), 'in'), "w4": ((8, 3, 5, 5), 'w'),
+              "a4": ((2, 6, 4, 4), 'in'), "g2": ((16, 64), 'grad')}
+    for name, (shape, ident) in shapes.items():
+        for dname, dt in DT.items():
+            x = from_bits(g[f"in_{name}_{dname}"], dt).view(shape).to(DEV)
+            for nbits in (8, 4):
+                c = cfg(sparsity_num_format='int', mant_bits=nbits, block_size=32)
+                y = bfp_ops.float_to_bfp_blocked(x, **c, identifier=ident)
+                assert y.dtype == torch.float32 and y.shape == x.shape
+                assert_bits_equal(bits(y), g[f"out_{name}_{dname}_b{nbits}"], torch.float32, f"int {name} {dname} b{nbits}")
+            if name in ("w2", "a3"):
+                flag = 'w_sparsity' if ident == 'w' else 'in_sparsity'
+                for first in ('s', 'q'):
+                    c = cfg(sparsity_num_format='int', mant_bits=8, block_size=32, first=first, sparsity_mode='structured', N=2, M=4, **{flag: True})
+                    y = bfp_ops.float_to_bfp_blocked(x, **c, identifier=ident)
+                    assert_bits_equal(bits(y), g[f"comp_{name}_{dname}_{first}_s"], torch.float32, f"int comp {name} {dname} {first}")
+
+
+def test_int_format_oracle_at_model_shapes():
+    for rows, cols, dname, ident in ((4096, 4096, "bf16", 'w'), (11008, 4096, "f16", 'w'), (1024, 20000, "f32", 'w'), (8 * 197, 1024, "f32", 'in')):
+        dt = DT[dname]
+        xc = synth(rows, cols, dt, 0.05 if ident == 'w' else 1.0)
+        c = cfg(sparsity_num_format='int', mant_bits=8, block_size=32)
+        got = bfp_ops.float_to_bfp_blocked(xc.to(DEV), **c, identifier=ident)
+        want = O.float_to_bfp_blocked(xc, **c, identifier=ident)
+        assert_bits_equal(bits(got), bits(want), torch.float32, f"int {rows}x{cols} {dname} {ident}")

@@ -167,3 +167,25 @@ def test_g8_nd():
         b = from_bits(g[f"mm_b_in_{dname}"], dt).view(2, 4, 32, 16)
         bq = O.float_to_bfp_blocked(b.transpose(-1, -2).contiguous(), **c, identifier='w').view(2, 4, 16, 32).transpose(-1, -2).contiguous()
         assert_bits_equal(bits(bq), g[f"mm_b_out_{dname}"], dt, "matmul transpose operand")
+
+
+def test_g9_int_format():
+    """'int' per-channel format (bfp_ops.py:111-120 -> int_ops.Quantizer): the reference returns fp32"""
+    g = load("g9_int.npz")
+    shapes = {"w2": ((48, 200), 'w'), "a2": ((33, 96), 'in'), "a3": ((2, 7, 96), 'in'), "w4": ((8, 3, 5, 5), 'w'),
+              "a4": ((2, 6, 4, 4), 'in'), "g2": ((16, 64), 'grad')}
+    for name, (shape, ident) in shapes.items():
+        for dname, dt in DT.items():
+            x = from_bits(g[f"in_{name}_{dname}"], dt).view(shape)
+            for nbits in (8, 4):
+                c = cfg(sparsity_num_format='int', mant_bits=nbits, block_size=32)
+                y = O.float_to_bfp_blocked(x, **c, identifier=ident)
+                assert y.dtype == torch.float32
+                assert_bits_equal(bits(y), g[f"out_{name}_{dname}_b{nbits}"], torch.float32, f"int {name} {dname} b{nbits}")
+            if name in ("w2", "a3"):
+                flag = 'w_sparsity' if ident == 'w' else 'in_sparsity'
+                for first in ('s', 'q'):
+                    for mode, extra in (("structured", dict(N=2, M=4)), ("unstructured", dict(sparsity_frac=0.5))):
+                        c = cfg(sparsity_num_format='int', mant_bits=8, block_size=32, first=first, sparsity_mode=mode, **{flag: True}, **extra)
+                        y = O.float_to_bfp_blocked(x, **c, identifier=ident)
+                        assert_bits_equal(bits(y), g[f"comp_{name}_{dname}_{first}_{mode[:1]}"], torch.float32, f"int comp {name} {dname} {first} {mode}")
