@@ -39,6 +39,9 @@ CASES = [
     ("general path: down_proj bf16 HBFP4 b64 4:8 s (k_nm_rows + k_quant_rows)", 4096, 11008, "bf16", 4, dict(w_sparsity=True, N=4, M=8)),
     ("general path: [4096,11000] bf16 HBFP4 b64 dense (ragged rows)", 4096, 11000, "bf16", 4, dict()),
     ("stochastic rounding: down_proj bf16 HBFP4 2:4 s", 4096, 11008, "bf16", 4, dict(w_sparsity=True, rounding_mode='stoc')),
+    ("int8 per-row: down_proj bf16 weights (fp32 out)", 4096, 11008, "bf16", 6, dict(sparsity_num_format='int', mant_bits=8)),
+    ("int8 per-column: activation [4096,4096] bf16 (fp32 out)", 4096, 4096, "bf16", 6, dict(sparsity_num_format='int', mant_bits=8, _ident='in')),
+    ("cfg3 tie-heavy input (already HBFP4) bf16 2:4 q", 4096, 11008, "bf16", 4, dict(w_sparsity=True, first='q', _prequant=True)),
 ]
 
 
@@ -56,11 +59,14 @@ def main():
             continue
         kw = dict(kw)
         ident = kw.pop("_ident", "w")
+        prequant = kw.pop("_prequant", False)
         c = cfg(**kw)
         dt = DT[dname]
         numel = rows * cols
         R = max(2, min(8, int(600e6 // (numel * (4 if dt == torch.float32 else 2))) or 2))
         ins = [(torch.randn(rows, cols, generator=torch.Generator().manual_seed(1234 + r)) * 0.02).to(dt).to(dev) for r in range(R)]
+        if prequant:      # inputs already on the HBFP4 grid: ~38 % of the 2:4 groups tie at the boundary
+            ins = [bfp_ops.float_to_bfp_blocked(x, **cfg(), identifier='w') for x in ins]
         L = args.launches
 
         def run():

@@ -163,9 +163,74 @@ __global__ void __launch_bounds__(kT) k_int_seg_quant(const void* in, float* out
     }
 }
 
+// weight path, vector flavour: inner % VEC == 0 and 16-B aligned rows -> 16-B loads, 16-B fp32 stores
+template <int DT, int G>
+__global__ void __launch_bounds__(kT) k_int_rows_vec(const void* in, float* out, int64_t C, int64_t inner, float maxq, float zero)
+{
+    constexpr int VEC = Traits<DT>::VEC;
+    __shared__ float s_mn[kT / 64], s_mx[kT / 64];
+    __shared__ int s_nan[kT / 64];
+    constexpr int PER_WG = kT / G;
+    const int sub = threadIdx.x / G, lig = threadIdx.x % G;
+    const int64_t ipr = inner / VEC;                               // lane items per row
+    auto load8 = [&](int64_t item, float* v) __attribute__((always_inline)) {
+        const uint4 q = reinterpret_cast<const uint4*>(in)[item];
+        if constexpr (VEC == 4) { v[0] = u2f(q.x); v[1] = u2f(q.y); v[2] = u2f(q.z); v[3] = u2f(q.w); }
+        else {
+            const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) { v[2 * j] = raw_to_f32<DT>(d[j] & 0xffffu); v[2 * j + 1] = raw_to_f32<DT>(d[j] >> 16); }
+        }
+    };
+    for (int64_t c0 = (int64_t)blockIdx.x * PER_WG; c0 < C; c0 += (int64_t)gridDim.x * PER_WG) {
+        const int64_t c = c0 + sub;
+        const bool live = c < C;
+        const int64_t base = (live ? c : 0) * ipr;
+        float mn = 0.0f, mx = 0.0f;
+        bool nan = false;
+        if (live)
+            for (int64_t i = lig; i < ipr; i += G) {
+                float v[VEC];
+                load8(base + i, v);
+#pragma unroll
+                for (int j = 0; j < VEC; j++) { nan |= v[j] != v[j]; mn = fminf(mn, v[j]); mx = fmaxf(mx, v[j]); }
+            }
+        wave_minmax(mn, mx, nan);
+        if constexpr (G > 64) {
+            const int w = threadIdx.x >> 6;
+            if ((threadIdx.x & 63) == 0) { s_mn[w] = mn; s_mx[w] = mx; s_nan[w] = nan; }
+            __syncthreads();
+            for (int i = 0; i < kT / 64; i++) { mn = fminf(mn, s_mn[i]); mx = fmaxf(mx, s_mx[i]); nan |= s_nan[i] != 0; }
+            __syncthreads();
+        }
+        if (nan) { mn = u2f(0x7fc00000u); mx = mn; }
+        const float scale = int_scale(mn, mx, maxq);
+        if (live)
+            for (int64_t i = lig; i < ipr; i += G) {
+                float v[VEC];
+                load8(base + i, v);
+#pragma unroll
+                for (int j = 0; j < VEC; j++) v[j] = int_q(v[j], scale, zero, maxq);
+                float4* o = reinterpret_cast<float4*>(out) + (base + i) * (VEC / 4);
+                o[0] = make_float4(v[0], v[1], v[2], v[3]);
+                if constexpr (VEC == 8) o[1] = make_float4(v[4], v[5], v[6], v[7]);
+            }
+    }
+}
+
 template <int DT>
 int run_int(const void* in, float* out, int64_t outer, int64_t C, int64_t inner, float maxq, float zero, uint32_t* ws, hipStream_t s)
 {
+    if (outer == 1 && inner % Traits<DT>::VEC == 0 &&
+        ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0) {
+        if (inner <= 16384) {
+            int64_t g = (C + 3) / 4;
+            hipLaunchKernelGGL((k_int_rows_vec<DT, 64>), dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(kT), 0, s, in, out, C, inner, maxq, zero);
+        } else {
+            hipLaunchKernelGGL((k_int_rows_vec<DT, 256>), dim3((unsigned)(C > 8192 ? 8192 : C)), dim3(kT), 0, s, in, out, C, inner, maxq, zero);
+        }
+        return (int)hipGetLastError();
+    }
     if (outer == 1) {
         if (inner <= 16384) {
             int64_t g = (C + 3) / 4;

@@ -958,7 +958,7 @@ template <int DT, int NM, bool SFIRST, bool STOCH>
 int launch_fused_l(const FusedArgs& a, hipStream_t s)
 {
     const bool deq_only = a.out_deq && !a.out_codes && !a.out_exp;
-    if constexpr (!STOCH) if (deq_only) return launch_fused_o<DT, NM, SFIRST, STOCH, true>(a, s);
+    if (deq_only) return launch_fused_o<DT, NM, SFIRST, STOCH, true>(a, s);
     return launch_fused_o<DT, NM, SFIRST, STOCH, false>(a, s);
 }
 
