@@ -44,6 +44,9 @@ enum {
 #define BFPQ_NM4_LUT_ENTRIES 729   /* uint8 keep-mask per 3^6 pairwise-comparison signature     */
 
 int bfpq_version(void);
+/* process-wide tuning knobs (measurement aid; defaults are the measured optimum on MI355X) */
+#define BFPQ_TUNE_MAX_GRID 0       /* cap on workgroups of the streaming kernels (default 1280) */
+int bfpq_tune(int key, int value);
 const char* bfpq_error_string(int code);
 
 /* ---- host-side table builders ---------------------------------------------------------------

@@ -33,7 +33,8 @@ namespace {
 #define BFPQ_NT 1                  // non-temporal loads/stores on the once-touched streams (A/B: +6..8 %)
 #endif
 constexpr int kThreads = 256;
-constexpr int kMaxGrid = BFPQ_MAXGRID;
+int g_max_grid = BFPQ_MAXGRID;           // tuning knob (bfpq_tune), process-wide
+#define kMaxGrid g_max_grid
 
 __device__ __forceinline__ uint4 stream_load(const uint4* p)
 {
@@ -1046,6 +1047,12 @@ bool fused_shape_ok(int64_t rows, int64_t cols, int dtype, int block_size, int N
 extern "C" {
 
 int bfpq_version(void) { return BFPQ_VERSION; }
+
+int bfpq_tune(int key, int value)
+{
+    if (key == BFPQ_TUNE_MAX_GRID && value >= 1 && value <= 65535) { g_max_grid = value; return 0; }
+    return BFPQ_E_ARG;
+}
 
 const char* bfpq_error_string(int code)
 {

@@ -58,6 +58,8 @@ def load_library():
             raise NativeUnavailable(f"cannot load {path}: {e}") from e
         vp, i64, i32, u64, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.c_double
         L.bfpq_version.restype = i32
+        L.bfpq_tune.argtypes = [i32, i32]
+        L.bfpq_tune.restype = i32
         L.bfpq_error_string.restype = ctypes.c_char_p
         L.bfpq_error_string.argtypes = [i32]
         L.bfpq_exp_window_host.argtypes = [i32, vp]
@@ -86,7 +88,7 @@ def load_library():
         return _lib
 
 
-EXPORTED_SYMBOLS = ("bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host",
+EXPORTED_SYMBOLS = ("bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
                     "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan",
                     "bfpq_tie_count", "bfpq_threshold_apply", "bfpq_quantize_threshold")

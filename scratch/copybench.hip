@@ -60,6 +60,42 @@ template <bool NT, int T, int U> __global__ void __launch_bounds__(T) k_gs_u(con
     }
 }
 
+// K4: grid-stride, each wave moves TWO ADJACENT 1-KB tiles per sweep (lane l: items base+l and base+64+l), one sweep ahead
+template <bool NT, int T> __global__ void __launch_bounds__(T) k_gs_adj2(const u4v* in, u4v* out, long n)
+{
+    const long wave = ((long)blockIdx.x * T + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const long nw = (long)gridDim.x * T / 64, last = n - 1;
+    long base = wave * 128 + lane;
+    u4v a = ld<NT>(in + (base < last ? base : last)), b = ld<NT>(in + (base + 64 < last ? base + 64 : last));
+    for (; base - lane < n; base += nw * 128) {
+        const long pf = base + nw * 128;
+        u4v na = ld<NT>(in + (pf < last ? pf : last)), nb = ld<NT>(in + (pf + 64 < last ? pf + 64 : last));
+        if (base < n) st<NT>(out + base, a);
+        if (base + 64 < n) st<NT>(out + base + 64, b);
+        a = na; b = nb;
+    }
+}
+// K5: 32 contiguous bytes per lane (two 16-B accesses at lane*32 and lane*32+16), one sweep ahead
+template <bool NT, int T> __global__ void __launch_bounds__(T) k_gs_wide(const u4v* in, u4v* out, long n)
+{
+    const long stride = (long)gridDim.x * T * 2, last = n - 1;
+    long base = ((long)blockIdx.x * T + threadIdx.x) * 2;
+    u4v a = ld<NT>(in + (base < last ? base : last)), b = ld<NT>(in + (base + 1 < last ? base + 1 : last));
+    for (; base < n; base += stride) {
+        const long pf = base + stride;
+        u4v na = ld<NT>(in + (pf < last ? pf : last)), nb = ld<NT>(in + (pf + 1 < last ? pf + 1 : last));
+        st<NT>(out + base, a);
+        if (base + 1 < n) st<NT>(out + base + 1, b);
+        a = na; b = nb;
+    }
+}
+// K6: like K0 but no prefetch (load, store)
+template <bool NT, int T> __global__ void __launch_bounds__(T) k_gs_nopf(const u4v* in, u4v* out, long n)
+{
+    const long stride = (long)gridDim.x * T;
+    for (long item = (long)blockIdx.x * T + threadIdx.x; item < n; item += stride) st<NT>(out + item, ld<NT>(in + item));
+}
+
 struct Var { std::string name; void (*fn)(const u4v*, u4v*, long); int grid, threads; };
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -95,6 +131,17 @@ int main()
     ADD("gs_u2 nt g2048", (k_gs_u<true, 256, 2>), 2048, 256);
     ADD("gs_u4 nt g512", (k_gs_u<true, 256, 4>), 512, 256);
     ADD("gs_u4 g1024", (k_gs_u<false, 256, 4>), 1024, 256);
+    ADD("gs_adj2 nt g1024", (k_gs_adj2<true, 256>), 1024, 256);
+    ADD("gs_adj2 nt g612", (k_gs_adj2<true, 256>), 612, 256);
+    ADD("gs_adj2 nt g2048", (k_gs_adj2<true, 256>), 2048, 256);
+    ADD("gs_wide nt g1024", (k_gs_wide<true, 256>), 1024, 256);
+    ADD("gs_wide nt g612", (k_gs_wide<true, 256>), 612, 256);
+    ADD("gs_nopf nt g1224", (k_gs_nopf<true, 256>), 1224, 256);
+    ADD("gs_nopf nt g2048", (k_gs_nopf<true, 256>), 2048, 256);
+    ADD("gs_nopf nt g4096", (k_gs_nopf<true, 256>), 4096, 256);
+    ADD("gs_pf1 nt g1224", (k_gs_pf1<true, 256>), 1224, 256);
+    ADD("gs_pf1 nt g1376", (k_gs_pf1<true, 256>), 1376, 256);
+    ADD("gs_pf1 nt g1101", (k_gs_pf1<true, 256>), 1101, 256);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<std::vector<float>> t(vars.size());
     for (int round = 0; round < ROUNDS; round++)

@@ -1,0 +1,47 @@
+"""The C ABI without Python/torch in the loop: tests/cabi/cabi_check.cpp is compiled with hipcc against
+include/bfpq.h + libbfpq.so (+ the oracle library as the checker) and run on the GPU.
+The CPU half checks argument validation through ctypes (no launch happens for a rejected call)."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+import quantization_sparsity_interplay_amd as pkg
+from quantization_sparsity_interplay_amd import native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_argument_validation_without_gpu():
+    L = pkg.load_library()
+    n = ctypes.c_void_p(0)
+    one = ctypes.c_void_p(16)               # a non-null, never dereferenced pointer: rejected before any launch
+    assert L.bfpq_quantize_nm(n, one, n, n, 4, 64, native.BF16, 64, 3, 1e-8, 2, 4, 1, 0, 0, one, one, n, n) == -1      # null input
+    assert L.bfpq_quantize_nm(one, n, n, n, 4, 64, native.BF16, 64, 3, 1e-8, 2, 4, 1, 0, 0, one, one, n, n) == -1      # no output
+    assert L.bfpq_quantize_nm(one, one, n, n, 4, 64, 9, 64, 3, 1e-8, 2, 4, 1, 0, 0, one, one, n, n) == -1              # bad dtype
+    assert L.bfpq_quantize_nm(one, one, n, n, 4, 64, native.BF16, 64, 3, 1e-8, 5, 4, 1, 0, 0, one, one, n, n) == -1    # N > M
+    assert L.bfpq_quantize_nm(one, one, n, n, 4, 64, native.BF16, 64, 3, 1e-8, 2, 65, 1, 0, 0, one, one, n, n) == -2   # M > 64
+    assert L.bfpq_quantize_nm(one, one, one, n, 4, 64, native.BF16, 64, 7, 1e-8, 0, 0, 1, 4, 0, one, one, n, n) == -1  # 4-bit codes, 7-bit mantissa
+    assert L.bfpq_quantize_nm(one, one, n, n, 4, 64, native.BF16, 64, 3, 1e-8, 0, 0, 1, 0, 0, n, one, n, n) == -1      # no exponent table
+    assert L.bfpq_quantize_nm(one, one, n, n, 0, 64, native.BF16, 64, 3, 1e-8, 2, 4, 1, 0, 0, one, one, n, n) == 0     # empty tensor: ok, no launch
+    assert L.bfpq_nm_sparsify(one, one, 4, 64, native.F32, 0, 4, one, n) == -1
+    assert L.bfpq_select_scan(native.BF16, 3, one, one, 5, n) == -1                                                     # pass out of range
+    assert L.bfpq_tie_workspace_elems(4096 * 11008, native.BF16) > 4096 * 11008 // 512
+    assert L.bfpq_int_quantize(one, one, 1, 4, 4, 5, 8, n, n) == -1
+    assert L.bfpq_tune(0, 0) == -1 and L.bfpq_tune(99, 5) == -1 and L.bfpq_tune(0, 1280) == 0
+    assert L.bfpq_is_fused(4, 64, 5, 64, 2, 4) == 0
+
+
+@pytest.mark.gpu
+def test_cabi_check_program(tmp_path):
+    exe = str(tmp_path / "cabi_check")
+    pkg_dir = os.path.join(ROOT, "quantization-sparsity-interplay_amd")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cabi", "cabi_check.cpp"), "-o", exe,
+                           "-L", pkg_dir, "-lbfpq", "-L", os.path.join(ROOT, "oracle"), "-lbfp_oracle",
+                           "-Wl,-rpath," + pkg_dir, "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(out.stdout, out.stderr)
+    assert out.returncode == 0 and "CABI CHECK PASSED" in out.stdout, out.stdout + out.stderr
