@@ -130,6 +130,73 @@ __global__ void __launch_bounds__(kT) k_int_cols_quant(const void* in, float* ou
     for (int64_t r = r0; r < r1; r++) out[r * C + col] = int_q(ldf<DT>(in, r * C + col), scale, zero, maxq);
 }
 
+// activation path, vector flavour (C % VEC == 0, 16-B aligned): thread owns VEC adjacent columns of a row chunk
+template <int DT>
+__device__ __forceinline__ void load_vec_f(const void* in, int64_t item, float* v)
+{
+    constexpr int VEC = Traits<DT>::VEC;
+    const uint4 q = reinterpret_cast<const uint4*>(in)[item];
+    if constexpr (VEC == 4) { v[0] = u2f(q.x); v[1] = u2f(q.y); v[2] = u2f(q.z); v[3] = u2f(q.w); }
+    else {
+        const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) { v[2 * j] = raw_to_f32<DT>(d[j] & 0xffffu); v[2 * j + 1] = raw_to_f32<DT>(d[j] >> 16); }
+    }
+}
+
+template <int DT>
+__global__ void __launch_bounds__(kT) k_int_cols_minmax_vec(const void* in, int64_t outer, int64_t C, int64_t rows_per_chunk, uint32_t* ws)
+{
+    constexpr int VEC = Traits<DT>::VEC;
+    const int64_t ipr = C / VEC;
+    const int64_t cg = (int64_t)blockIdx.x * kT + threadIdx.x;
+    if (cg >= ipr) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < outer ? r0 + rows_per_chunk : outer;
+    float mn[VEC], mx[VEC];
+    bool nan[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) { mn[j] = 0.0f; mx[j] = 0.0f; nan[j] = false; }
+#pragma unroll 8
+    for (int64_t r = r0; r < r1; r++) {                    // independent loads: unrolled so that several are in flight
+        float v[VEC];
+        load_vec_f<DT>(in, r * ipr + cg, v);
+#pragma unroll
+        for (int j = 0; j < VEC; j++) { nan[j] |= v[j] != v[j]; mn[j] = fminf(mn[j], v[j]); mx[j] = fmaxf(mx[j], v[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+        if (nan[j]) { mn[j] = u2f(0xffc00000u); mx[j] = u2f(0x7fc00000u); }
+        atomicMin(&ws[cg * VEC + j], f_key(mn[j]));
+        atomicMax(&ws[C + cg * VEC + j], f_key(mx[j]));
+    }
+}
+
+template <int DT>
+__global__ void __launch_bounds__(kT) k_int_cols_quant_vec(const void* in, float* out, int64_t outer, int64_t C, int64_t rows_per_chunk,
+                                                           const uint32_t* ws, float maxq, float zero)
+{
+    constexpr int VEC = Traits<DT>::VEC;
+    const int64_t ipr = C / VEC;
+    const int64_t cg = (int64_t)blockIdx.x * kT + threadIdx.x;
+    if (cg >= ipr) return;
+    float scale[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) scale[j] = int_scale(key_f(ws[cg * VEC + j]), key_f(ws[C + cg * VEC + j]), maxq);
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < outer ? r0 + rows_per_chunk : outer;
+#pragma unroll 4
+    for (int64_t r = r0; r < r1; r++) {
+        float v[VEC];
+        load_vec_f<DT>(in, r * ipr + cg, v);
+#pragma unroll
+        for (int j = 0; j < VEC; j++) v[j] = int_q(v[j], scale[j], zero, maxq);
+        float4* o = reinterpret_cast<float4*>(out) + (r * ipr + cg) * (VEC / 4);
+        o[0] = make_float4(v[0], v[1], v[2], v[3]);
+        if constexpr (VEC == 8) o[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
 // 4-D activation path: one wave per (outer, channel) segment of `inner` contiguous elements
 template <int DT>
 __global__ void __launch_bounds__(kT) k_int_seg_minmax(const void* in, int64_t outer, int64_t C, int64_t inner, uint32_t* ws)
@@ -245,7 +312,23 @@ int run_int(const void* in, float* out, int64_t outer, int64_t C, int64_t inner,
     if (e != hipSuccess) return (int)e;
     e = hipMemsetAsync(ws + C, 0x00, sizeof(uint32_t) * C, s);                   // max keys start at the bottom
     if (e != hipSuccess) return (int)e;
-    if (inner == 1) {
+    if (inner == 1 && C % Traits<DT>::VEC == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0) {
+        const int64_t ipr = C / Traits<DT>::VEC;
+        const int64_t gx = (ipr + kT - 1) / kT;
+        auto chunking = [&](int64_t min_rows, int64_t target_wgs, int64_t* rpc_out) {
+            int64_t chunks = target_wgs / gx;
+            if (chunks < 1) chunks = 1;
+            if (chunks > (outer + min_rows - 1) / min_rows) chunks = (outer + min_rows - 1) / min_rows;
+            if (chunks > 65535) chunks = 65535;
+            *rpc_out = (outer + chunks - 1) / chunks;
+            return (unsigned)((outer + *rpc_out - 1) / *rpc_out);
+        };
+        // min/max: every thread ends with 2*VEC atomics, so give it at least 32 rows; quantize: no atomics, fine chunks
+        int64_t rpc_mm, rpc_q;
+        const unsigned gy_mm = chunking(32, 1024, &rpc_mm), gy_q = chunking(4, 2048, &rpc_q);
+        hipLaunchKernelGGL((k_int_cols_minmax_vec<DT>), dim3((unsigned)gx, gy_mm), dim3(kT), 0, s, in, outer, C, rpc_mm, ws);
+        hipLaunchKernelGGL((k_int_cols_quant_vec<DT>), dim3((unsigned)gx, gy_q), dim3(kT), 0, s, in, out, outer, C, rpc_q, (const uint32_t*)ws, maxq, zero);
+    } else if (inner == 1) {
         int64_t chunks = (outer + 63) / 64;
         if (chunks > 1024) chunks = 1024;
         const int64_t rpc = (outer + chunks - 1) / chunks;

@@ -542,6 +542,35 @@ __global__ void __launch_bounds__(128) k_nm_rows(const void* in, void* out, void
         const int64_t c0 = gi * M;
         const int n = (int)((cols - c0) < M ? (cols - c0) : M);
         const int64_t base = row * cols + c0;
+        constexpr int EPV = 16 / (int)sizeof(raw_t);                       // elements per 16-byte vector
+        // whole groups that are 16-byte multiples at 16-byte aligned addresses move as vectors
+        const bool vec_io = !codes && (M % EPV) == 0 && (cols % M) == 0 &&
+                            ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+        if (vec_io) {
+            for (int q = 0; q < M / EPV; q++) {
+                const uint4 v = reinterpret_cast<const uint4*>(src + base)[q];
+                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < EPV; e++) {
+                    const uint32_t r = sizeof(raw_t) == 4 ? d[e] : ((d[e >> 1] >> (16 * (e & 1))) & 0xffffu);
+                    view.set(q * EPV + e, ((uint64_t)mag_key<DT>(r) << 8) | (uint64_t)(q * EPV + e));
+                }
+            }
+            const uint64_t prune = nm_prune_mask(view, N, M);
+            for (int q = 0; q < M / EPV; q++) {
+                uint4 v = reinterpret_cast<const uint4*>(src + base)[q];
+                uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < EPV; e++) {
+                    if ((prune >> (q * EPV + e)) & 1ull) {
+                        if (sizeof(raw_t) == 4) d[e] = 0u;
+                        else d[e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+                    }
+                }
+                reinterpret_cast<uint4*>(dst + base)[q] = make_uint4(d[0], d[1], d[2], d[3]);
+            }
+            continue;
+        }
         for (int i = 0; i < M; i++) {
             const uint32_t key = i < n ? mag_key<DT>((uint32_t)src[base + i]) : 0u;
             view.set(i, ((uint64_t)key << 8) | (uint64_t)i);
@@ -613,6 +642,90 @@ __global__ void __launch_bounds__(kThreads) k_quant_rows(const void* in, void* o
             }
         }
         if (out_exp && valid && lig == 0) out_exp[b] = sat_exp(bs);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_quant_rows_vec: HBFP quantizer for rows that are 16-byte aligned (cols % VEC == 0, block % VEC == 0,
+// aligned pointers) but whose length is NOT a multiple of the block, or whose block is not a power-of-two
+// number of lane items.  A block owns GP = pow2ceil(block / VEC) adjacent lanes; lane j of the group holds
+// lane item j of the block when that item exists in the row (else zeros: the reference's F.pad).  One
+// pass, registers only.  Virtual item v = (row * nblk + blk) * GP + j.
+// ---------------------------------------------------------------------------------------------
+template <int DT>
+__global__ void __launch_bounds__(kThreads) k_quant_rows_vec(const void* in, void* out_deq, void* out_codes, int8_t* out_exp,
+                                                             int64_t rows, int64_t cols, int block, int GP,
+                                                             int mant_bits, float eps_dt, int code_bits, uint64_t seed,
+                                                             const uint8_t* exp_win)
+{
+    using T = Traits<DT>;
+    constexpr int VEC = T::VEC;
+    __shared__ uint8_t s_win[BFPQ_EXP_WIN_ENTRIES];
+    for (int i = threadIdx.x; i < BFPQ_EXP_WIN_ENTRIES; i += kThreads) s_win[i] = exp_win[i];
+    __syncthreads();
+    const bool stoch = seed != 0;
+    const int64_t ipr = cols / VEC;                         // lane items per row
+    const int ipb = block / VEC;                            // lane items per (full) block
+    const int64_t nblk = (cols + block - 1) / block;
+    const int64_t total = rows * nblk * GP;                 // virtual items
+    const int64_t total_round = (total + 63) / 64 * 64;
+    const int j = threadIdx.x % GP;
+    for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < total_round; v += (int64_t)gridDim.x * kThreads) {
+        const int64_t b = v / GP;                           // global block index (GP is a power of two: a shift)
+        const int64_t row = b / nblk, blk = b - row * nblk;
+        const int64_t it = blk * ipb + j;                   // lane item inside the row
+        const bool valid = v < total && j < ipb && it < ipr;
+        const int64_t item = row * ipr + it;
+        uint32_t raw[VEC];
+        {
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (valid) q = reinterpret_cast<const uint4*>(in)[item];
+            if constexpr (VEC == 4) { raw[0] = q.x; raw[1] = q.y; raw[2] = q.z; raw[3] = q.w; }
+            else {
+                raw[0] = q.x & 0xffffu; raw[1] = q.x >> 16; raw[2] = q.y & 0xffffu; raw[3] = q.y >> 16;
+                raw[4] = q.z & 0xffffu; raw[5] = q.z >> 16; raw[6] = q.w & 0xffffu; raw[7] = q.w >> 16;
+            }
+        }
+        uint32_t mx = 0;
+#pragma unroll
+        for (int e = 0; e < VEC; e++) { const uint32_t k = raw[e] & T::ABS; mx = k > mx ? k : mx; }
+        for (int o = 1; o < GP; o <<= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)mx, o, 64); mx = other > mx ? other : mx; }
+        const BlockScale bs = block_scale<DT>(mx, mant_bits, eps_dt, s_win);
+        if (!valid) continue;
+        float y[VEC], code[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) {
+            const float dither = stoch ? uniform24(seed, (uint64_t)item * VEC + e) - 0.5f : 0.f;
+            y[e] = quant_elem<DT>(raw_to_f32<DT>(raw[e]), bs, stoch, dither, &code[e]);
+        }
+        if (out_deq) {
+            uint32_t o[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; e++) o[e] = f32_to_raw<DT>(y[e]);
+            uint4 w;
+            if constexpr (VEC == 4) w = make_uint4(o[0], o[1], o[2], o[3]);
+            else w = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
+            reinterpret_cast<uint4*>(out_deq)[item] = w;
+        }
+        if (out_codes) {
+            int c[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; e++) c[e] = (int)code[e];
+            if (code_bits == 4) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int e = 0; e < VEC; e++) w |= ((uint32_t)c[e] & 0xfu) << (4 * e);
+                if constexpr (VEC == 8) reinterpret_cast<uint32_t*>(out_codes)[item] = w;
+                else reinterpret_cast<uint16_t*>(out_codes)[item] = (uint16_t)w;
+            } else if (code_bits == 8) {
+#pragma unroll
+                for (int e = 0; e < VEC; e++) reinterpret_cast<int8_t*>(out_codes)[item * VEC + e] = (int8_t)c[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; e++) reinterpret_cast<int16_t*>(out_codes)[item * VEC + e] = (int16_t)c[e];
+            }
+        }
+        if (out_exp && j == 0) out_exp[b] = sat_exp(bs);
     }
 }
 
@@ -1016,6 +1129,17 @@ int launch_quant_rows(const void* in, void* out_deq, void* out_codes, int8_t* ou
 {
     const int64_t total = rows * ((cols + block - 1) / block);
     if (total == 0) return 0;
+    const int vec = dtype_vec(dtype);
+    const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out_deq) | reinterpret_cast<uintptr_t>(out_codes)) & 15u) == 0;
+    if (aligned && cols % vec == 0 && block % vec == 0 && block / vec <= 64 && (code_bits != 4 || cols % 2 == 0)) {
+        int GP = 1;
+        while (GP < block / vec) GP <<= 1;
+        const int grid = grid_for(total * GP);
+        if (dtype == BFPQ_F32) hipLaunchKernelGGL((k_quant_rows_vec<BFPQ_F32>), dim3(grid), dim3(kThreads), 0, s, in, out_deq, out_codes, out_exp, rows, cols, block, GP, mant_bits, eps_dt, code_bits, seed, exp_win);
+        else if (dtype == BFPQ_F16) hipLaunchKernelGGL((k_quant_rows_vec<BFPQ_F16>), dim3(grid), dim3(kThreads), 0, s, in, out_deq, out_codes, out_exp, rows, cols, block, GP, mant_bits, eps_dt, code_bits, seed, exp_win);
+        else hipLaunchKernelGGL((k_quant_rows_vec<BFPQ_BF16>), dim3(grid), dim3(kThreads), 0, s, in, out_deq, out_codes, out_exp, rows, cols, block, GP, mant_bits, eps_dt, code_bits, seed, exp_win);
+        return (int)hipGetLastError();
+    }
     int G = 1;
     while (G < 64 && 2 * G < block) G <<= 1;       // two elements per lane per step
     const int grid = grid_for(total * G);
@@ -1148,23 +1272,40 @@ int bfpq_quantize_nm(const void* in, void* out_deq, void* out_codes, int8_t* out
         return launch_fused<BFPQ_BF16>(a, M, sparsify_first != 0, s);
     }
 
-    // general path: separate launches
+    // general path: separate launches.  The quantize stage still takes the flat fused kernel when the shape
+    // allows it (e.g. M = 8 on a regular weight: only the N:M replay needs the general kernel).
     if (out_codes && code_bits == 4 && ((block_size & 1) || (M & 1))) return BFPQ_E_UNSUPPORTED;
+    auto quantize_stage = [&](const void* src, void* deq) -> int {
+        const bool al = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(deq) | reinterpret_cast<uintptr_t>(out_codes)) & 15u) == 0;
+        if (al && fused_shape_ok(rows, cols, dtype, block_size, 0, 0)) {
+            FusedArgs a;
+            a.in = src; a.out_deq = deq; a.out_codes = out_codes; a.out_exp = out_exp;
+            a.n_items = rows * cols / dtype_vec(dtype);
+            a.exp_win = exp_win; a.nm_lut = nullptr; a.seed = stoch_seed; a.eps_dt = eps_dt;
+            a.lpb = block_size / dtype_vec(dtype);
+            a.mant_bits = mant_bits; a.N = 0; a.code_bits = code_bits;
+            a.force_slow = mant_bits > (dtype == BFPQ_F32 ? 24 : (dtype == BFPQ_F16 ? 11 : 8));
+            a.sel = nullptr; a.tie_counts = nullptr; a.tie_base = nullptr;
+            if (dtype == BFPQ_F32) return launch_fused<BFPQ_F32>(a, 0, true, s);
+            if (dtype == BFPQ_F16) return launch_fused<BFPQ_F16>(a, 0, true, s);
+            return launch_fused<BFPQ_BF16>(a, 0, true, s);
+        }
+        return launch_quant_rows(src, deq, out_codes, out_exp, rows, cols, dtype, block_size, mant_bits, eps_dt, code_bits, stoch_seed, exp_win, s);
+    };
     if (block_size == 0) {                                               // sparsify only
         if (!out_deq) return BFPQ_E_ARG;
         return launch_nm_rows(in, out_deq, nullptr, 0, rows, cols, dtype, N, M, s);
     }
-    if (M == 0)
-        return launch_quant_rows(in, out_deq, out_codes, out_exp, rows, cols, dtype, block_size, mant_bits, eps_dt, code_bits, stoch_seed, exp_win, s);
+    if (M == 0) return quantize_stage(in, out_deq);
     void* tmp = out_deq ? out_deq : scratch;
     if (!tmp) return BFPQ_E_ARG;
     int rc;
     if (sparsify_first) {
         rc = launch_nm_rows(in, tmp, nullptr, 0, rows, cols, dtype, N, M, s);
         if (rc) return rc;
-        return launch_quant_rows(tmp, out_deq, out_codes, out_exp, rows, cols, dtype, block_size, mant_bits, eps_dt, code_bits, stoch_seed, exp_win, s);
+        return quantize_stage(tmp, out_deq);
     }
-    rc = launch_quant_rows(in, tmp, out_codes, out_exp, rows, cols, dtype, block_size, mant_bits, eps_dt, code_bits, stoch_seed, exp_win, s);
+    rc = quantize_stage(in, tmp);
     if (rc) return rc;
     return launch_nm_rows(tmp, tmp, out_codes, code_bits, rows, cols, dtype, N, M, s);
 }
