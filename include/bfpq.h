@@ -149,6 +149,13 @@ int64_t bfpq_int_workspace_elems(int64_t C);
 int bfpq_int_quantize(const void* in_dev, float* out_dev, int64_t outer, int64_t C, int64_t inner, int dtype, int bits,
                       uint32_t* ws_dev, void* stream);
 
+/* ---- packed HBFP -> tensor (no counterpart in the reference, which never stores quantized tensors;
+ * SURVEY §8f next #3): out = code * 2^(exp - mant_bits) in dtype, from the codes / exponents that
+ * bfpq_quantize_nm / bfpq_quantize_threshold write.  Equals their out_deq except that a negative zero
+ * comes back as +0 (a two's-complement code has no -0) and saturated exponents (|e| > 127) are lost. */
+int bfpq_dequantize(const void* codes_dev, const int8_t* exp_dev, void* out_dev, int64_t rows, int64_t cols, int dtype,
+                    int block_size, int mant_bits, int code_bits, void* stream);
+
 /* layout of state_dev as read back by a host that wants tau / counts (all little-endian) */
 typedef struct bfpq_select_state {
     uint32_t prefix;      /* magnitude bits decided so far (high digits)                         */

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from .. import native
 
 __all__ = ["rounding_modes", "round_tensor", "get_exponent", "float_to_bfp_blocked", "float_to_bfp_packed",
-           "sparsify", "unpack_bfp_args", "F_linear_bfp", "F_matmul_bfp", "BFPLinear", "BFPConv2d", "WeightCache"]
+           "sparsify", "unpack_bfp_args", "F_linear_bfp", "F_matmul_bfp", "BFPLinear", "BFPConv2d", "WeightCache", "PackedBFP"]
 
 
 class rounding_modes:
@@ -210,6 +210,50 @@ def float_to_bfp_packed(t, mant_bits, block_size, epsilon=1e-8, N=0, M=0, first=
     deq, codes, exps = native.quantize_nm(t, block_size, mant_bits, epsilon, N=N, M=M, sparsify_first=(first == 's'),
                                           want_deq=with_dequant, code_bits=code_bits, want_exp=True)
     return (codes, exps, deq.view(t.shape)) if with_dequant else (codes, exps)
+
+
+class PackedBFP:
+    """A tensor in packed HBFP form: integer mantissas + one int8 exponent per block (+ what is needed to
+    decode it).  N:M / unstructured pruning needs no extra field: pruned elements are zero codes."""
+
+    def __init__(self, codes, exps, shape, dtype, mant_bits, block_size, code_bits):
+        self.codes, self.exps = codes, exps
+        self.shape, self.dtype = tuple(shape), dtype
+        self.mant_bits, self.block_size, self.code_bits = int(mant_bits), int(block_size), int(code_bits)
+
+    @classmethod
+    def quantize(cls, t, mant_bits, block_size, epsilon=1e-8, N=0, M=0, first='s', code_bits=None):
+        if code_bits is None:
+            code_bits = 4 if mant_bits <= 3 else (8 if mant_bits <= 7 else 16)
+        codes, exps = float_to_bfp_packed(t, mant_bits, block_size, epsilon, N, M, first, code_bits)
+        return cls(codes, exps, t.shape, t.dtype, mant_bits, block_size, code_bits)
+
+    def dequantize(self, out=None):
+        """== the reference's fake-quantised tensor (a -0.0 there is +0.0 here)"""
+        cols = self.shape[-1] if len(self.shape) else 1
+        return native.dequantize(self.codes, self.exps, cols, self.dtype, self.block_size, self.mant_bits, self.code_bits,
+                                 out=None if out is None else out.view(-1, cols)).view(self.shape)
+
+    def nbytes(self):
+        return self.codes.numel() * self.codes.element_size() + self.exps.numel()
+
+    def save(self, path):
+        """safetensors file: tensors `codes`, `exps`; the rest as string metadata"""
+        from safetensors.torch import save_file
+        meta = dict(format="hbfp-packed-v1", shape=",".join(str(d) for d in self.shape), dtype=str(self.dtype).replace("torch.", ""),
+                    mant_bits=str(self.mant_bits), block_size=str(self.block_size), code_bits=str(self.code_bits))
+        save_file({"codes": self.codes.cpu().contiguous(), "exps": self.exps.cpu().contiguous()}, path, metadata=meta)
+
+    @classmethod
+    def load(cls, path, device="cuda"):
+        from safetensors import safe_open
+        with safe_open(path, framework="pt", device="cpu") as f:
+            meta = f.metadata()
+            assert meta.get("format") == "hbfp-packed-v1", meta
+            codes, exps = f.get_tensor("codes"), f.get_tensor("exps")
+        shape = tuple(int(d) for d in meta["shape"].split(",")) if meta["shape"] else ()
+        return cls(codes.to(device), exps.to(device), shape, getattr(torch, meta["dtype"]), int(meta["mant_bits"]),
+                   int(meta["block_size"]), int(meta["code_bits"]))
 
 
 # ---- module / functional wrappers (reference: bfp_ops.py:151-287) -----------------------------

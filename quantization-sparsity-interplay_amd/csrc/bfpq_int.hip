@@ -346,7 +346,71 @@ int run_int(const void* in, float* out, int64_t outer, int64_t C, int64_t inner,
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// packed HBFP -> tensor: out = code * 2^(e - mant_bits) (exact in the dtype by construction; exponent -128
+// marks a block the quantizer turned into NaN).  Lane item = VEC elements, as everywhere else.
+// ---------------------------------------------------------------------------------------------
+template <int DT>
+__global__ void __launch_bounds__(kT) k_dequant(const void* codes, const int8_t* exps, void* out, int64_t rows, int64_t cols,
+                                                int block, int mant_bits, int code_bits)
+{
+    using raw_t = typename Traits<DT>::raw_t;
+    constexpr int VEC = Traits<DT>::VEC;
+    const int64_t nblk = (cols + block - 1) / block;
+    const int64_t crow = code_bits == 4 ? (cols + 1) / 2 : cols;          // code bytes (4-bit) or entries per row
+    const int64_t ipr = (cols + VEC - 1) / VEC;                           // lane items per row (last one may be ragged)
+    const int64_t total = rows * ipr;
+    const bool vec_ok = cols % VEC == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+    for (int64_t v = (int64_t)blockIdx.x * kT + threadIdx.x; v < total; v += (int64_t)gridDim.x * kT) {
+        const int64_t row = v / ipr, it = v - row * ipr;
+        uint32_t o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+            const int64_t c = it * VEC + j;
+            int code = 0, e = 0;
+            if (c < cols) {
+                e = exps[row * nblk + c / block];
+                if (code_bits == 4) {
+                    const uint32_t b = reinterpret_cast<const uint8_t*>(codes)[row * crow + c / 2];
+                    code = (int)((b >> (4 * (c & 1))) & 0xfu);
+                    if (code > 7) code -= 16;
+                } else if (code_bits == 8) code = reinterpret_cast<const int8_t*>(codes)[row * crow + c];
+                else code = reinterpret_cast<const int16_t*>(codes)[row * crow + c];
+            }
+            const float val = e == -128 ? u2f(0x7fc00000u) : ldexpf((float)code, e - mant_bits);
+            o[j] = f32_to_raw<DT>(val);
+        }
+        if (vec_ok) {
+            uint4 w;
+            if constexpr (VEC == 4) w = make_uint4(o[0], o[1], o[2], o[3]);
+            else w = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
+            reinterpret_cast<uint4*>(out)[row * ipr + it] = w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; j++)
+                if (it * VEC + j < cols) reinterpret_cast<raw_t*>(out)[row * cols + it * VEC + j] = (raw_t)o[j];
+        }
+    }
+}
+
 extern "C" {
+
+int bfpq_dequantize(const void* codes, const int8_t* exps, void* out, int64_t rows, int64_t cols, int dtype,
+                    int block_size, int mant_bits, int code_bits, void* stream)
+{
+    if (rows < 0 || cols < 0 || dtype < 0 || dtype > 2 || block_size <= 0 || mant_bits < 0 || mant_bits > 15) return BFPQ_E_ARG;
+    if (!(code_bits == 4 || code_bits == 8 || code_bits == 16)) return BFPQ_E_ARG;
+    if (rows * cols == 0) return 0;
+    if (!codes || !exps || !out) return BFPQ_E_ARG;
+    const int vec = dtype == BFPQ_F32 ? 4 : 8;
+    int64_t g = (rows * ((cols + vec - 1) / vec) + kT - 1) / kT;
+    const dim3 grid((unsigned)(g > 2048 ? 2048 : g));
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == BFPQ_F32) hipLaunchKernelGGL((k_dequant<BFPQ_F32>), grid, dim3(kT), 0, s, codes, exps, out, rows, cols, block_size, mant_bits, code_bits);
+    else if (dtype == BFPQ_F16) hipLaunchKernelGGL((k_dequant<BFPQ_F16>), grid, dim3(kT), 0, s, codes, exps, out, rows, cols, block_size, mant_bits, code_bits);
+    else hipLaunchKernelGGL((k_dequant<BFPQ_BF16>), grid, dim3(kT), 0, s, codes, exps, out, rows, cols, block_size, mant_bits, code_bits);
+    return (int)hipGetLastError();
+}
 
 int64_t bfpq_int_workspace_elems(int64_t C) { return C < 0 ? BFPQ_E_ARG : 2 * C; }
 

@@ -148,3 +148,14 @@ def gather_overlapped(local, rows_total, compute, chunks=4, group=None):
     if on_gpu:
         torch.cuda.current_stream(local.device).wait_stream(side)
     return out
+
+
+def all_gather_packed(local, rows_total, mant_bits, block_size, group=None, dequantize=True, **kw):
+    """Quantize this rank's slab to packed HBFP, all-gather the PACKED bytes (codes + exponents: ~0.52 B per
+    element for HBFP4 instead of 2 B), and decode locally.  Returns the full fake-quantised tensor
+    (dequantize=True) or the gathered PackedBFP."""
+    p = bfp_ops.PackedBFP.quantize(local, mant_bits, block_size, **kw)
+    codes = all_gather_rows(p.codes, rows_total, group)
+    exps = all_gather_rows(p.exps, rows_total, group)
+    full = bfp_ops.PackedBFP(codes, exps, (rows_total,) + tuple(local.shape[1:]), local.dtype, mant_bits, block_size, p.code_bits)
+    return full.dequantize() if dequantize else full

@@ -80,15 +80,16 @@ def load_library():
         L.bfpq_int_workspace_elems.argtypes = [i64]
         L.bfpq_int_workspace_elems.restype = i64
         L.bfpq_int_quantize.argtypes = [vp, vp, i64, i64, i64, i32, i32, vp, vp]
+        L.bfpq_dequantize.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, i32, vp]
         for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
                      "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan", "bfpq_tie_count",
-                     "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize"):
+                     "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize"):
             getattr(L, name).restype = i32
         _lib = L
         return _lib
 
 
-EXPORTED_SYMBOLS = ("bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host",
+EXPORTED_SYMBOLS = ("bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
                     "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan",
                     "bfpq_tie_count", "bfpq_threshold_apply", "bfpq_quantize_threshold")
@@ -334,3 +335,21 @@ def int_quantize(t, bits, weight):
         check(L.bfpq_int_quantize(_ptr(src), _ptr(out), outer, C, inner, DTYPE_CODE[src.dtype], int(bits), _ptr(ws), _stream(src)),
               "bfpq_int_quantize")
     return out
+
+
+def dequantize(codes, exps, cols, dtype, block_size, mant_bits, code_bits, out=None):
+    """packed codes + exponents -> [rows, cols] tensor of `dtype` (bfpq_dequantize)"""
+    if exps.device.type != "cuda" or codes.device != exps.device:
+        raise NativeUnavailable("packed codes / exponents must live on one ROCm device")
+    if dtype not in DTYPE_CODE:
+        raise TypeError(f"unsupported dtype {dtype}")
+    L = load_library()
+    rows = exps.shape[0]
+    dst = out if out is not None else torch.empty((rows, cols), dtype=dtype, device=exps.device)
+    if rows * cols == 0:
+        return dst
+    with torch.cuda.device(exps.device):
+        c, e = codes.contiguous(), exps.contiguous()
+        check(L.bfpq_dequantize(_ptr(c), _ptr(e), _ptr(dst), rows, int(cols), DTYPE_CODE[dtype], int(block_size), int(mant_bits),
+                                int(code_bits), ctypes.c_void_p(torch.cuda.current_stream(exps.device).cuda_stream)), "bfpq_dequantize")
+    return dst

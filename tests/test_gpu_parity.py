@@ -507,3 +507,28 @@ def test_random_configs_vs_oracle():
             else:
                 xq = O.no_sparsity_float_to_bfp(xc, blk, m)
                 _tie_class_check(xq, got, frac, dt, what)
+
+
+def test_packed_format_dequantize_and_safetensors(tmp_path):
+    """§8f next #3: packed HBFP -> tensor decode, and the on-disk form (safetensors) round trip"""
+    for dname, m, blk, cols in (("bf16", 3, 64, 1024), ("f16", 7, 32, 1024), ("f32", 3, 16, 520), ("bf16", 3, 64, 1000)):
+        dt = DT[dname]
+        xc = synth(128, cols, dt)
+        x = xc.to(DEV)
+        for first in ('s', 'q'):
+            p = bfp_ops.PackedBFP.quantize(x, m, blk, N=2, M=4, first=first)
+            want = bfp_ops.float_to_bfp_blocked(x, **cfg(mant_bits=m, block_size=blk, w_sparsity=True, first=first), identifier='w')
+            got = p.dequantize()
+            assert got.dtype == dt and got.shape == x.shape
+            assert torch.equal(got.float(), want.float())                    # value-equal (-0.0 == +0.0)
+            nz = want != 0
+            assert_bits_equal(bits(got).reshape(-1)[nz.cpu().view(-1).numpy()], bits(want).reshape(-1)[nz.cpu().view(-1).numpy()], dt, "packed decode")
+            f = tmp_path / f"w_{dname}_{first}.safetensors"
+            p.save(str(f))
+            q = bfp_ops.PackedBFP.load(str(f), DEV)
+            assert q.shape == p.shape and q.dtype == dt and q.mant_bits == m and q.block_size == blk
+            assert torch.equal(q.dequantize(), got)
+            assert p.nbytes() < x.numel() * x.element_size() * (0.27 if m <= 3 else 0.53) * (1 if dt != torch.float32 else 0.5) + 4096
+    # NaN blocks survive the packed form
+    xh = torch.zeros(4, 64, dtype=torch.float16, device=DEV)
+    assert bool(torch.isnan(bfp_ops.PackedBFP.quantize(xh, 3, 64).dequantize()).all())
