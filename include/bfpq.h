@@ -74,7 +74,9 @@ uint64_t bfpq_nm_prune_mask_host(const uint32_t* keys, int N, int M);
  * Outputs (each nullable, at least one required):
  *   out_deq_dev   [rows, cols] dtype          the reference's fake-quantised tensor (drop-in mode)
  *   out_codes_dev sign-magnitude mantissas as two's-complement integers, code_bits wide
- *                 (4: two per byte, low nibble first, [rows, ceil(cols/2)] bytes; 8: int8; 16: int16)
+ *                 (4: two per byte, low nibble first, [rows, ceil(cols/2)] bytes; 8: int8; 16: int16;
+ *                 32: not codes but the fp32 image of the dequantised tensor, [rows, cols] float -- what the
+ *                 reference returns for 'stoc' rounding of a half tensor; single-pass kernel only)
  *   out_exp_dev   int8 [rows, ceil(cols/block)] shared exponent e (value = code * 2^(e-mant_bits));
  *                 saturated to [-127, 127]; -128 marks a block the reference turns into NaN
  * Any shape, block size and 1 <= N <= M <= 64 is accepted; the single-pass fused kernel is used

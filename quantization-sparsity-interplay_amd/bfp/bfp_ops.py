@@ -34,6 +34,19 @@ def _seed_for(mode):
     raise NotImplementedError("Rounding mode %s is not implemented", mode)
 
 
+def _quantize_nm_ref_dtype(t, block_size, mant_bits, epsilon, rounding_mode, N=0, M=0, sparsify_first=True):
+    """quantize_nm with the reference's output dtype: 'stoc' on a half tensor comes back as fp32.
+    The single-pass kernel writes that fp32 image directly; other shapes convert afterwards."""
+    seed = _seed_for(rounding_mode)
+    src = t.contiguous()
+    if seed and t.dtype != torch.float32 and t.numel() and block_size > 0 and native.is_fused(src, block_size, N, M):
+        _, y, _ = native.quantize_nm(src, block_size, mant_bits, epsilon, N=N, M=M, sparsify_first=sparsify_first,
+                                     want_deq=False, code_bits=32, stoch_seed=seed)
+        return y.view(t.shape)
+    y, _, _ = native.quantize_nm(src, block_size, mant_bits, epsilon, N=N, M=M, sparsify_first=sparsify_first, stoch_seed=seed)
+    return _stoc_dtype(y.view(t.shape), rounding_mode)
+
+
 def _stoc_dtype(t, mode):
     """reference quirk: 'stoc' adds fp32 noise, so a half input comes back as fp32"""
     return t.float() if (mode == rounding_modes.STOC and t.dtype != torch.float32) else t
@@ -70,8 +83,7 @@ def _convert_blocked_float_to_bfp(t, mant_bits, epsilon, rounding_mode, device):
 def _no_sparsity_float_to_bfp(t, block_size, mant_bits, epsilon, rounding_mode, device):
     """reference: bfp_ops.py:46-59 -- blocks of block_size along the last dim, zero-padded per row"""
     native.require_device_tensor(t)
-    y, _, _ = native.quantize_nm(t, block_size, mant_bits, epsilon, stoch_seed=_seed_for(rounding_mode))
-    return _stoc_dtype(y.view(t.shape), rounding_mode)
+    return _quantize_nm_ref_dtype(t, block_size, mant_bits, epsilon, rounding_mode)
 
 
 _select_ws = {}
@@ -167,9 +179,8 @@ def float_to_bfp_blocked(t, mant_bits, epsilon, rounding_mode, device, block_siz
         assert ((N > 0) and (M > 0) and (N <= M))
         native.require_device_tensor(t)
         mb = weight_mant_bits if sgd_update else mant_bits
-        y, _, _ = native.quantize_nm(t, block_size, mb, epsilon, N=N if N < M else 0, M=M if N < M else 0,
-                                     sparsify_first=(first == 's'), stoch_seed=_seed_for(rounding_mode))
-        return _stoc_dtype(y.view(t.shape), rounding_mode)
+        return _quantize_nm_ref_dtype(t, block_size, mb, epsilon, rounding_mode, N=N if N < M else 0, M=M if N < M else 0,
+                                      sparsify_first=(first == 's'))
 
     if sparsity and sparsity_mode == 'unstructured' and sparsity_num_format == 'bfp' and first == 's':
         # global threshold (radix select), then prune + quantize in ONE pass over the tensor

@@ -133,16 +133,21 @@ __device__ __forceinline__ BlockScale block_scale(uint32_t max_key, int mant_bit
 }
 
 // counter-based uniform in [0,1) with 24 bits, keyed by (seed, element index): one round of a
-// 32-bit integer mixer (multiply / xor-shift) over the index -- 9 integer ops, no state
-__device__ __forceinline__ float uniform24(uint64_t seed, uint64_t idx)
+// 32-bit integer mixer (multiply / xor-shift) over the index -- no state.  rng_item_key() does the 64-bit
+// part once per lane item, uniform24k() the 7-op per-element part.
+__device__ __forceinline__ uint32_t rng_item_key(uint64_t seed, uint64_t idx0)
 {
-    uint32_t x = (uint32_t)idx * 0x9E3779B9u + (uint32_t)seed;
-    x += (uint32_t)(idx >> 32) * 0x85EBCA6Bu + (uint32_t)(seed >> 32);
+    return (uint32_t)idx0 * 0x9E3779B9u + (uint32_t)seed + (uint32_t)(idx0 >> 32) * 0x85EBCA6Bu + (uint32_t)(seed >> 32);
+}
+__device__ __forceinline__ float uniform24k(uint32_t key, uint32_t j)
+{
+    uint32_t x = key + j * 0x9E3779B9u;
     x ^= x >> 16; x *= 0x7FEB352Du;
     x ^= x >> 15; x *= 0x846CA68Bu;
     x ^= x >> 16;
     return (float)(x >> 8) * 5.9604644775390625e-08f;
 }
+__device__ __forceinline__ float uniform24(uint64_t seed, uint64_t idx) { return uniform24k(rng_item_key(seed, idx), 0u); }
 
 // One element through _convert_blocked_float_to_bfp (:40-44).  Returns the dequantised value
 // (exactly representable in dtype) and the integer mantissa in *code.

@@ -402,7 +402,7 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
                 uint32_t outraw[VEC];
 #pragma unroll
                 for (int j = 0; j < VEC; j++) {
-                    const float dither = STOCH ? uniform24(a.seed, (uint64_t)item * VEC + j) - 0.5f : 0.f;
+                    const float dither = STOCH ? uniform24k(rng_item_key(a.seed, (uint64_t)item * VEC), (uint32_t)j) - 0.5f : 0.f;
                     const float yv = quant_elem<DT>(raw_to_f32<DT>(raw[j]), bs, STOCH, dither, &code[j]);
                     outraw[j] = f32_to_raw<DT>(yv);
                 }
@@ -414,6 +414,7 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
             } else {
                 typedef float float2v __attribute__((ext_vector_type(2)));
                 float y[VEC];
+                [[maybe_unused]] const uint32_t rkey = STOCH ? rng_item_key(a.seed, (uint64_t)item * VEC) : 0u;
 #pragma unroll
                 for (int j = 0; j < VEC; j += 2) {                     // two elements per v_pk_mul_f32
                     float2v x;
@@ -423,8 +424,8 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
                     } else x = (float2v){raw_to_f32<DT>(raw[j]), raw_to_f32<DT>(raw[j + 1])};
                     float2v t = x * (float2v){fs.inv, fs.inv};
                     if constexpr (STOCH) {
-                        t.x += uniform24(a.seed, (uint64_t)item * VEC + j) - 0.5f;
-                        t.y += uniform24(a.seed, (uint64_t)item * VEC + j + 1) - 0.5f;
+                        t.x += uniform24k(rkey, (uint32_t)j) - 0.5f;
+                        t.y += uniform24k(rkey, (uint32_t)j + 1u) - 0.5f;
                     }
                     float2v q = {__builtin_amdgcn_fmed3f(rintf(t.x), -fs.qmax, fs.qmax), __builtin_amdgcn_fmed3f(rintf(t.y), -fs.qmax, fs.qmax)};
                     code[j] = q.x; code[j + 1] = q.y;
@@ -474,6 +475,15 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
                 for (int j = 0; j < VEC; j++) w |= ((uint32_t)c[j] & 0xfu) << (4 * j);
                 if constexpr (VEC == 8) reinterpret_cast<uint32_t*>(a.out_codes)[item] = w;
                 else reinterpret_cast<uint16_t*>(a.out_codes)[item] = (uint16_t)w;
+            } else if (a.code_bits == 32) {                              // fp32 image of the dequantised values
+                const uint32_t od[4] = {o0, o1, o2, o3};
+                uint32_t f[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; j++)
+                    f[j] = VEC == 4 ? od[j] : f2u(raw_to_f32<DT>((od[j >> 1] >> (16 * (j & 1))) & 0xffffu));
+                uint4* dst = reinterpret_cast<uint4*>(a.out_codes) + item * (VEC / 4);
+                dst[0] = make_uint4(f[0], f[1], f[2], f[3]);
+                if constexpr (VEC == 8) dst[1] = make_uint4(f[4], f[5], f[6], f[7]);
             } else if (a.code_bits == 8) {
                 uint32_t w0 = 0, w1 = 0;
 #pragma unroll
@@ -1250,7 +1260,7 @@ int bfpq_quantize_nm(const void* in, void* out_deq, void* out_codes, int8_t* out
     if (rows * cols == 0) return 0;
     if (!in || (!out_deq && !out_codes && !out_exp)) return BFPQ_E_ARG;
     if (block_size > 0 && (mant_bits < 0 || mant_bits > 23 || !exp_win)) return BFPQ_E_ARG;
-    if (out_codes && !(code_bits == 4 || code_bits == 8 || code_bits == 16)) return BFPQ_E_ARG;
+    if (out_codes && !(code_bits == 4 || code_bits == 8 || code_bits == 16 || code_bits == 32)) return BFPQ_E_ARG;
     if (out_codes && block_size == 0) return BFPQ_E_ARG;
     if (out_codes && ((code_bits == 4 && mant_bits > 3) || (code_bits == 8 && mant_bits > 7) || (code_bits == 16 && mant_bits > 15))) return BFPQ_E_ARG;
     if (block_size == 0 && M == 0) return BFPQ_E_ARG;                   // identity: the caller returns its input
@@ -1272,6 +1282,7 @@ int bfpq_quantize_nm(const void* in, void* out_deq, void* out_codes, int8_t* out
         return launch_fused<BFPQ_BF16>(a, M, sparsify_first != 0, s);
     }
 
+    if (out_codes && code_bits == 32) return BFPQ_E_UNSUPPORTED;       // fp32 image: fused kernel only
     // general path: separate launches.  The quantize stage still takes the flat fused kernel when the shape
     // allows it (e.g. M = 8 on a regular weight: only the N:M replay needs the general kernel).
     if (out_codes && code_bits == 4 && ((block_size & 1) || (M & 1))) return BFPQ_E_UNSUPPORTED;

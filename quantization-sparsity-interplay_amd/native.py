@@ -187,6 +187,8 @@ def quantize_nm(t, block_size, mant_bits, epsilon, N=0, M=0, sparsify_first=True
                 codes = torch.empty((rows, (cols + 1) // 2), dtype=torch.uint8, device=dev)
             elif code_bits == 8:
                 codes = torch.empty((rows, cols), dtype=torch.int8, device=dev)
+            elif code_bits == 32:
+                codes = torch.empty((rows, cols), dtype=torch.float32, device=dev)
             else:
                 codes = torch.empty((rows, cols), dtype=torch.int16, device=dev)
         if want_exp and block_size > 0:
@@ -353,3 +355,9 @@ def dequantize(codes, exps, cols, dtype, block_size, mant_bits, code_bits, out=N
         check(L.bfpq_dequantize(_ptr(c), _ptr(e), _ptr(dst), rows, int(cols), DTYPE_CODE[dtype], int(block_size), int(mant_bits),
                                 int(code_bits), ctypes.c_void_p(torch.cuda.current_stream(exps.device).cuda_stream)), "bfpq_dequantize")
     return dst
+
+
+def is_fused(t, block_size, N=0, M=0):
+    """would quantize_nm take the single-pass kernel for this (contiguous) tensor?"""
+    rows, cols = rows_cols(t)
+    return bool(load_library().bfpq_is_fused(rows, cols, DTYPE_CODE[t.dtype], int(block_size), int(N), int(M))) and t.data_ptr() % 16 == 0
