@@ -96,6 +96,29 @@ template <bool NT, int T> __global__ void __launch_bounds__(T) k_gs_nopf(const u
     for (long item = (long)blockIdx.x * T + threadIdx.x; item < n; item += stride) st<NT>(out + item, ld<NT>(in + item));
 }
 
+// K7: K0 with an XCD-aware block remap: XCD x (blocks b % 8 == x) streams a contiguous eighth of every sweep
+template <bool NT, int T> __global__ void __launch_bounds__(T) k_gs_pf1_xcd(const u4v* in, u4v* out, long n)
+{
+    const long G = gridDim.x, q = G / 8, r = G % 8, x = blockIdx.x % 8;
+    const long bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + blockIdx.x / 8;     // bijective for any G
+    const long stride = G * T, last = n - 1;
+    long item = bid * T + threadIdx.x;
+    u4v cur = ld<NT>(in + (item < last ? item : last));
+    for (; item < n; item += stride) {
+        const long pf = item + stride;
+        u4v nxt = ld<NT>(in + (pf < last ? pf : last));
+        st<NT>(out + item, cur);
+        cur = nxt;
+    }
+}
+template <bool NT, int T> __global__ void __launch_bounds__(T) k_flat_xcd(const u4v* in, u4v* out, long n)
+{
+    const long G = gridDim.x, q = G / 8, r = G % 8, x = blockIdx.x % 8;
+    const long bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + blockIdx.x / 8;
+    const long item = bid * T + threadIdx.x;
+    if (item < n) st<NT>(out + item, ld<NT>(in + item));
+}
+
 struct Var { std::string name; void (*fn)(const u4v*, u4v*, long); int grid, threads; };
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
@@ -131,6 +154,12 @@ int main()
     ADD("gs_u2 nt g2048", (k_gs_u<true, 256, 2>), 2048, 256);
     ADD("gs_u4 nt g512", (k_gs_u<true, 256, 4>), 512, 256);
     ADD("gs_u4 g1024", (k_gs_u<false, 256, 4>), 1024, 256);
+    ADD("gs_pf1_xcd nt g1224", (k_gs_pf1_xcd<true, 256>), 1224, 256);
+    ADD("gs_pf1_xcd nt g1024", (k_gs_pf1_xcd<true, 256>), 1024, 256);
+    ADD("gs_pf1_xcd nt g2048", (k_gs_pf1_xcd<true, 256>), 2048, 256);
+    ADD("gs_pf1_xcd nt g2448", (k_gs_pf1_xcd<true, 256>), 2448, 256);
+    ADD("gs_pf1_xcd g1224", (k_gs_pf1_xcd<false, 256>), 1224, 256);
+    ADD("flat_xcd nt", (k_flat_xcd<true, 256>), gfull256, 256);
     ADD("gs_adj2 nt g1024", (k_gs_adj2<true, 256>), 1024, 256);
     ADD("gs_adj2 nt g612", (k_gs_adj2<true, 256>), 612, 256);
     ADD("gs_adj2 nt g2048", (k_gs_adj2<true, 256>), 2048, 256);

@@ -532,3 +532,22 @@ def test_packed_format_dequantize_and_safetensors(tmp_path):
     # NaN blocks survive the packed form
     xh = torch.zeros(4, 64, dtype=torch.float16, device=DEV)
     assert bool(torch.isnan(bfp_ops.PackedBFP.quantize(xh, 3, 64).dequantize()).all())
+
+
+def test_large_tensor_parity():
+    """0.5 GiB bf16 weight (268 M elements, ~200 sweeps per workgroup): full-tensor oracle comparison for the fused
+    kernel, and the unstructured path's counts at that size"""
+    rows, cols = 16384, 16384
+    g = torch.Generator().manual_seed(4321)
+    xc = (torch.randn(rows, cols, generator=g, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+    x = xc.to(DEV)
+    c = cfg(w_sparsity=True)
+    got = bfp_ops.float_to_bfp_blocked(x, **c, identifier='w')
+    want = O.float_to_bfp_blocked(xc, **c, identifier='w')
+    assert torch.equal(got.cpu().view(torch.int16), want.view(torch.int16))
+    del want
+    ys = bfp_ops._unstructured_sparsity(x, 'cuda', 0.5)
+    assert int((ys == 0).sum()) == rows * cols // 2                       # exactly k pruned (no zeros in the input)
+    kept_min = float(ys.float().abs()[ys != 0].min())
+    pruned_max = float(x.float().abs()[ys == 0].max())
+    assert pruned_max <= kept_min
