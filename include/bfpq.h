@@ -45,7 +45,7 @@ enum {
 
 int bfpq_version(void);
 /* process-wide tuning knobs (measurement aid; defaults are the measured optimum on MI355X) */
-#define BFPQ_TUNE_MAX_GRID 0       /* cap on workgroups of the streaming kernels (default 1280) */
+#define BFPQ_TUNE_MAX_GRID 0       /* cap on workgroups of the streaming kernels (default 1024) */
 int bfpq_tune(int key, int value);
 const char* bfpq_error_string(int code);
 

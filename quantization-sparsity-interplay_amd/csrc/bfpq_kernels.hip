@@ -27,7 +27,7 @@ using namespace bfpq;
 namespace {
 
 #ifndef BFPQ_MAXGRID
-#define BFPQ_MAXGRID 1280          // 256 CUs x 5 workgroups, grid-stride beyond that (A/B: 1024-1280 best, 2048 -5 %)
+#define BFPQ_MAXGRID 1024          // 256 CUs x 4 workgroups, grid-stride beyond that (A/B over 5 shapes: 1024 best or tied)
 #endif
 #ifndef BFPQ_NT
 #define BFPQ_NT 1                  // non-temporal loads/stores on the once-touched streams (A/B: +6..8 %)
