@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turn a gpurun_out/prof/ directory (written by scratch/prof.sh on the GPU box) into the committed
+"""Turn a gpurun_out/prof/ directory (written by tools_dev/prof.sh on the GPU box) into the committed
 summaries under profiles/: kernel stats CSV, PMC traffic markdown and traffic.json (read by bench.py).
 usage: python profiles/collect.py <round-tag> [bench-json]"""
 import csv, glob, json, os, shutil, sys
@@ -27,7 +27,7 @@ bench = json.load(open(sys.argv[2])) if len(sys.argv) > 2 else None
 bt = json.load(open(os.path.join(prof, "bench_trace.json")))
 md = f"""# {tag} -- rocprofv3 evidence for the headline kernel
 
-Commands (scratch/prof.sh; each counter in its own pass, kernel-trace/stats in a third; run from /tmp on the GPU box):
+Commands (tools_dev/prof.sh; each counter in its own pass, kernel-trace/stats in a third; run from /tmp on the GPU box):
 
     rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace -- python3 bench.py --no-cpu-baseline --steps 200 --warmup 20
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof/pmc_fetch -- python3 bench.py --no-cpu-baseline --steps 50 --warmup 5 --eager

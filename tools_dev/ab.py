@@ -1,5 +1,5 @@
 """A/B harness: several builds of libbfpq.so in ONE process, interleaved rounds, hipGraph of L launches each.
-usage: python scratch/ab.py name=path.so ...   (headline workload)"""
+usage: python tools_dev/ab.py name=path.so ...   (headline workload)"""
 import ctypes, sys, statistics, torch
 sys.path.insert(0, '.')
 from quantization_sparsity_interplay_amd import native
