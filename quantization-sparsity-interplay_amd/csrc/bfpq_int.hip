@@ -150,9 +150,8 @@ __global__ void __launch_bounds__(kT) k_int_cols_minmax_vec(const void* in, int6
     constexpr int VEC = Traits<DT>::VEC;
     const int64_t ipr = C / VEC;
     const int64_t cg = (int64_t)blockIdx.x * kT + threadIdx.x;
-    if (cg >= ipr) return;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
-    const int64_t r1 = r0 + rows_per_chunk < outer ? r0 + rows_per_chunk : outer;
+    const int64_t r1 = cg < ipr ? (r0 + rows_per_chunk < outer ? r0 + rows_per_chunk : outer) : r0;   // idle lanes: empty range
     float mn[VEC], mx[VEC];
     bool nan[VEC];
 #pragma unroll
@@ -164,11 +163,24 @@ __global__ void __launch_bounds__(kT) k_int_cols_minmax_vec(const void* in, int6
 #pragma unroll
         for (int j = 0; j < VEC; j++) { nan[j] |= v[j] != v[j]; mn[j] = fminf(mn[j], v[j]); mx[j] = fmaxf(mx[j], v[j]); }
     }
+    // transpose through LDS so that one atomic wave-instruction covers 64 consecutive columns (256 contiguous
+    // bytes): lane-strided atomics are an order of magnitude slower (MI355X_MICROARCH.md, global atomics)
+    __shared__ uint32_t s_mn[kT * VEC], s_mx[kT * VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
         if (nan[j]) { mn[j] = u2f(0xffc00000u); mx[j] = u2f(0x7fc00000u); }
-        atomicMin(&ws[cg * VEC + j], f_key(mn[j]));
-        atomicMax(&ws[C + cg * VEC + j], f_key(mx[j]));
+        s_mn[threadIdx.x * VEC + j] = f_key(mn[j]);
+        s_mx[threadIdx.x * VEC + j] = f_key(mx[j]);
+    }
+    __syncthreads();
+    const int64_t col0 = (int64_t)blockIdx.x * kT * VEC;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+        const int64_t col = col0 + j * kT + threadIdx.x;
+        if (col < C) {
+            atomicMin(&ws[col], s_mn[j * kT + threadIdx.x]);
+            atomicMax(&ws[C + col], s_mx[j * kT + threadIdx.x]);
+        }
     }
 }
 
