@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import native
+from .. import ops as _ops          # registers torch.ops.bfpq.* (traceable entry points)
 
 __all__ = ["rounding_modes", "round_tensor", "get_exponent", "float_to_bfp_blocked", "float_to_bfp_packed",
            "sparsify", "unpack_bfp_args", "F_linear_bfp", "F_matmul_bfp", "BFPLinear", "BFPConv2d", "WeightCache", "PackedBFP"]
@@ -38,6 +39,8 @@ def _quantize_nm_ref_dtype(t, block_size, mant_bits, epsilon, rounding_mode, N=0
     """quantize_nm with the reference's output dtype: 'stoc' on a half tensor comes back as fp32.
     The single-pass kernel writes that fp32 image directly; other shapes convert afterwards."""
     seed = _seed_for(rounding_mode)
+    if seed == 0:                                      # round-half-even: the registered (traceable) op
+        return torch.ops.bfpq.fake_quantize(t, int(block_size), int(mant_bits), float(epsilon), int(N), int(M), bool(sparsify_first), 0)
     src = t.contiguous()
     if seed and t.dtype != torch.float32 and t.numel() and block_size > 0 and native.is_fused(src, block_size, N, M):
         _, y, _ = native.quantize_nm(src, block_size, mant_bits, epsilon, N=N, M=M, sparsify_first=sparsify_first,

@@ -292,6 +292,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "g8_nd_linear.npz"), **g8)
 
     write_g9(ops)
+    write_g10()
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("golden fixtures written, total bytes:", tot, "torch", torch.__version__)
 
@@ -326,8 +327,38 @@ def write_g9(ops):
     np.savez_compressed(os.path.join(HERE, "g9_int.npz"), **g9)
 
 
+def write_g10():
+    """G10: the reference's BFPAdam (bfp_optim_lstm.py:12-93) for three steps on CPU, 'determ' rounding,
+    weight_mant_bits = 15 (the wide-mantissa weight grid of HBFP training)"""
+    load_ref()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("refbfp.bfp_util", f"{REF}/bfp_util.py")
+    util = importlib.util.module_from_spec(spec); sys.modules["refbfp.bfp_util"] = util; spec.loader.exec_module(util)
+    spec = importlib.util.spec_from_file_location("refbfp.bfp_optim_lstm", f"{REF}/bfp_optim_lstm.py")
+    optm = importlib.util.module_from_spec(spec); sys.modules["refbfp.bfp_optim_lstm"] = optm; spec.loader.exec_module(optm)
+    g10 = {}
+    gen = torch.Generator().manual_seed(2025)
+    for tag, amsgrad in (("plain", False), ("ams", True)):
+        params = [torch.nn.Parameter(torch.randn(64, 128, generator=gen) * 0.05), torch.nn.Parameter(torch.randn(96, generator=gen) * 0.05)]
+        opt = optm.BFPAdam(params, lr=1e-2, amsgrad=amsgrad)
+        opt.bfp_args = cfg(mant_bits=7, weight_mant_bits=15, block_size=32)          # the YAML on disk says device 'cuda' / 'stoc'
+        for i, p_ in enumerate(params):
+            g10[f"{tag}_p{i}_init"] = bits(p_.data)
+        for step in range(3):
+            for i, p_ in enumerate(params):
+                gr = torch.randn(p_.shape, generator=gen) * 0.1
+                g10[f"{tag}_g{i}_s{step}"] = bits(gr)
+                p_.grad = gr
+            opt.step()
+            for i, p_ in enumerate(params):
+                g10[f"{tag}_p{i}_s{step}"] = bits(p_.data)
+    np.savez_compressed(os.path.join(HERE, "g10_bfpadam.npz"), **g10)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "g9":
         write_g9(load_ref())
+    elif len(sys.argv) > 1 and sys.argv[1] == "g10":
+        write_g10()
     else:
         main()

@@ -1,0 +1,62 @@
+"""BFPAdam (reference bfp_optim_lstm.py:12-93).  CPU: the class with the oracle injected as its quantizer reproduces
+the reference's own three steps (golden G10) bit for bit.  GPU: the same class on the HIP engine lands on the same
+parameters up to the last-bit differences of the GPU's Adam arithmetic (at most one grid step after the snap)."""
+import numpy as np
+import pytest
+import torch
+
+from quantization_sparsity_interplay_amd.bfp.bfp_optim_lstm import BFPAdam
+from util import load, from_bits, bits
+from oracle import oracle as O
+
+
+def cfg():
+    return dict(mant_bits=7, epsilon=1e-8, rounding_mode='determ', device='cpu', block_size=32, num_format='bfp',
+                weight_mant_bits=15, in_sparsity=False, w_sparsity=False, grad_sparsity=False, sparsity_frac=0.5, N=2, M=4,
+                sparsity_num_format='bfp', first='s', sparsity_mode='structured')
+
+
+def _run(device, quantize_fn, tag, amsgrad):
+    g = load("g10_bfpadam.npz")
+    params = [torch.nn.Parameter(from_bits(g[f"{tag}_p0_init"], torch.float32).view(64, 128).to(device)),
+              torch.nn.Parameter(from_bits(g[f"{tag}_p1_init"], torch.float32).view(96).to(device))]
+    opt = BFPAdam(params, lr=1e-2, amsgrad=amsgrad, bfp_args=cfg(), quantize_fn=quantize_fn)
+    out = []
+    for step in range(3):
+        for i, p in enumerate(params):
+            p.grad = from_bits(g[f"{tag}_g{i}_s{step}"], torch.float32).view(p.shape).to(device)
+        opt.step()
+        out.append([p.detach().cpu().clone() for p in params])
+    return g, out
+
+
+@pytest.mark.parametrize("tag,amsgrad", [("plain", False), ("ams", True)])
+def test_bfpadam_matches_reference_steps_cpu(tag, amsgrad):
+    g, out = _run("cpu", O.float_to_bfp_blocked, tag, amsgrad)
+    for step in range(3):
+        for i in range(2):
+            assert np.array_equal(bits(out[step][i]).reshape(-1), g[f"{tag}_p{i}_s{step}"].reshape(-1)), (tag, step, i)
+
+
+def test_bfpadam_config_errors():
+    p = [torch.nn.Parameter(torch.zeros(4, 32))]
+    opt = BFPAdam(p, bfp_args=dict(cfg(), num_format='int8'))
+    p[0].grad = torch.ones(4, 32)
+    with pytest.raises(NotImplementedError):
+        opt.step()
+    opt = BFPAdam(p, bfp_args=dict(cfg(), num_format='fp32'))            # plain Adam, never touches the engine
+    opt.step()
+    assert torch.isfinite(p[0]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,amsgrad", [("plain", False), ("ams", True)])
+def test_bfpadam_gpu(tag, amsgrad):
+    g, out = _run("cuda:0", None, tag, amsgrad)
+    for step in range(3):
+        for i in range(2):
+            want = from_bits(g[f"{tag}_p{i}_s{step}"], torch.float32).view(out[step][i].shape)
+            got = out[step][i]
+            # grid step of HBFP16 in a block with |max| ~ 0.2: 2^(e-15) ~ 8e-6; allow one step, require almost all equal
+            assert float((got - want).abs().max()) <= 2.0 ** -15
+            assert float((got == want).float().mean()) > 0.97

@@ -551,3 +551,17 @@ def test_large_tensor_parity():
     kept_min = float(ys.float().abs()[ys != 0].min())
     pruned_max = float(x.float().abs()[ys == 0].max())
     assert pruned_max <= kept_min
+
+
+def test_torch_library_ops_and_compile():
+    """the engine's entry points are registered torch ops: opcheck's fake-tensor rule holds and a patched module
+    compiles (aot_eager backend: no code generation involved) to the same result as eager"""
+    x = synth(64, 256, torch.bfloat16).to(DEV)
+    y = torch.ops.bfpq.fake_quantize(x, 64, 3, 1e-8, 2, 4, True, 0)
+    want = O.float_to_bfp_blocked(x.cpu(), **cfg(w_sparsity=True), identifier='w')
+    assert_bits_equal(bits(y), bits(want), torch.bfloat16, "registered op")
+    torch.library.opcheck(torch.ops.bfpq.fake_quantize, (x, 64, 3, 1e-8, 2, 4, True, 0), test_utils=("test_schema", "test_faketensor"))
+    lin = bfp_ops.BFPLinear(256, 128, True, **cfg(mant_bits=7, block_size=32, w_sparsity=True)).to(DEV).to(torch.bfloat16)
+    eager = lin(x)
+    compiled = torch.compile(lin, backend="aot_eager", fullgraph=True)(x)
+    assert torch.equal(eager, compiled)
