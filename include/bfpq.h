@@ -158,6 +158,17 @@ int bfpq_int_quantize(const void* in_dev, float* out_dev, int64_t outer, int64_t
 int bfpq_dequantize(const void* codes_dev, const int8_t* exp_dev, void* out_dev, int64_t rows, int64_t cols, int dtype,
                     int block_size, int mant_bits, int code_bits, void* stream);
 
+/* ---- packed-format consumer for decode (no reference counterpart: it runs F.linear on fake-quantised tensors,
+ * bfp_ops.py:187-190): out[t][n] = sum_k x[t][k] W[n][k], T <= 16 tokens, W packed HBFP
+ * (4-bit codes, mant_bits <= 3) and x packed HBFP (int8 codes, mant_bits <= 7), both block 64, exact integer
+ * block sums on the int8 matrix cores, fp32 across blocks.  N % 16 == 0, K % 256 == 0.
+ *   xcodes_dev [16, K] int8 and xexp_dev [16, K/64] (rows >= T: any content, their results are discarded),
+ *   slabs_dev [bfpq_hbfp_linear_slices(N, K), 16, N] fp32 scratch, out_dev [T, N] of out_dtype. */
+int bfpq_hbfp_linear_slices(int64_t N, int64_t K);
+int bfpq_hbfp_linear_decode(const void* wcodes_dev, const int8_t* wexp_dev, const int8_t* xcodes_dev, const int8_t* xexp_dev,
+                            void* out_dev, float* slabs_dev, int64_t T, int64_t N, int64_t K,
+                            int out_dtype, int w_mant_bits, int x_mant_bits, void* stream);
+
 /* layout of state_dev as read back by a host that wants tau / counts (all little-endian) */
 typedef struct bfpq_select_state {
     uint32_t prefix;      /* magnitude bits decided so far (high digits)                         */

@@ -251,6 +251,13 @@ class PackedBFP:
     def nbytes(self):
         return self.codes.numel() * self.codes.element_size() + self.exps.numel()
 
+    def linear_decode(self, x, x_mant_bits=7, epsilon=1e-8):
+        """x @ W^T for <= 16 tokens straight from the packed weight (self is W [N, K], 4-bit codes, block 64):
+        the activation is quantized to HBFP(x_mant_bits + 1) block 64 and every block's dot product is an exact
+        integer sum on the int8 matrix cores (native.hbfp_linear_decode)."""
+        assert self.code_bits == 4 and self.block_size == 64 and len(self.shape) == 2
+        return native.hbfp_linear_decode(x, self.codes, self.exps, self.mant_bits, x_mant_bits, epsilon)
+
     def save(self, path):
         """safetensors file: tensors `codes`, `exps`; the rest as string metadata"""
         from safetensors.torch import save_file

@@ -81,15 +81,18 @@ def load_library():
         L.bfpq_int_workspace_elems.restype = i64
         L.bfpq_int_quantize.argtypes = [vp, vp, i64, i64, i64, i32, i32, vp, vp]
         L.bfpq_dequantize.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, i32, vp]
+        L.bfpq_hbfp_linear_slices.argtypes = [i64, i64]
+        L.bfpq_hbfp_linear_decode.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
         for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
                      "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan", "bfpq_tie_count",
-                     "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize"):
+                     "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize", "bfpq_hbfp_linear_slices",
+                     "bfpq_hbfp_linear_decode"):
             getattr(L, name).restype = i32
         _lib = L
         return _lib
 
 
-EXPORTED_SYMBOLS = ("bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host",
+EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
                     "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan",
                     "bfpq_tie_count", "bfpq_threshold_apply", "bfpq_quantize_threshold")
@@ -164,7 +167,7 @@ def _ptr(t):
 
 
 def quantize_nm(t, block_size, mant_bits, epsilon, N=0, M=0, sparsify_first=True, want_deq=True, code_bits=0,
-                want_exp=False, stoch_seed=0, out=None):
+                want_exp=False, stoch_seed=0, out=None, codes_out=None, exps_out=None):
     """Launch bfpq_quantize_nm on t's device/stream.  Returns (deq | None, codes | None, exps | None)."""
     require_device_tensor(t)
     L = load_library()
@@ -182,7 +185,9 @@ def quantize_nm(t, block_size, mant_bits, epsilon, N=0, M=0, sparsify_first=True
         if want_deq:
             deq = out if out is not None else torch.empty_like(src)
         codes = exps = None
-        if code_bits:
+        if code_bits and codes_out is not None:
+            codes = codes_out                                  # caller-owned, contiguous, right shape
+        elif code_bits:
             if code_bits == 4:
                 codes = torch.empty((rows, (cols + 1) // 2), dtype=torch.uint8, device=dev)
             elif code_bits == 8:
@@ -191,7 +196,9 @@ def quantize_nm(t, block_size, mant_bits, epsilon, N=0, M=0, sparsify_first=True
                 codes = torch.empty((rows, cols), dtype=torch.float32, device=dev)
             else:
                 codes = torch.empty((rows, cols), dtype=torch.int16, device=dev)
-        if want_exp and block_size > 0:
+        if want_exp and block_size > 0 and exps_out is not None:
+            exps = exps_out
+        elif want_exp and block_size > 0:
             exps = torch.empty((rows, (cols + block_size - 1) // block_size), dtype=torch.int8, device=dev)
         win = exp_window_dev(src.dtype, dev) if block_size > 0 else None
         lut = nm4_lut_dev(N, dev) if M == 4 else None
@@ -361,3 +368,31 @@ def is_fused(t, block_size, N=0, M=0):
     """would quantize_nm take the single-pass kernel for this (contiguous) tensor?"""
     rows, cols = rows_cols(t)
     return bool(load_library().bfpq_is_fused(rows, cols, DTYPE_CODE[t.dtype], int(block_size), int(N), int(M))) and t.data_ptr() % 16 == 0
+
+
+def hbfp_linear_decode(x, wcodes, wexps, w_mant_bits, x_mant_bits=7, epsilon=1e-8, out_dtype=None):
+    """out = x @ W^T for <= 16 tokens, W given as packed HBFP (4-bit codes [N, K/2], int8 exponents [N, K/64], block 64),
+    x quantized on the fly to HBFP(x_mant_bits + 1) block 64; integer block dot products on the int8 matrix cores."""
+    require_device_tensor(x)
+    L = load_library()
+    K = x.shape[-1]
+    T = x.numel() // K
+    N = wexps.shape[0]
+    slices = L.bfpq_hbfp_linear_slices(N, K)
+    if T < 1 or T > 16 or slices < 0:
+        raise ValueError(f"hbfp_linear_decode needs 1..16 tokens, N % 16 == 0 and K % 256 == 0 (got T={T}, N={N}, K={K})")
+    dev = x.device
+    out_dtype = out_dtype or x.dtype
+    with torch.cuda.device(dev):
+        # the activation quantizer writes straight into the 16-row operand buffers (rows >= T stay uninitialised:
+        # each token's results live in its own lanes and rows >= T are never read back)
+        xc16 = torch.empty((16, K), dtype=torch.int8, device=dev)
+        xe16 = torch.empty((16, K // 64), dtype=torch.int8, device=dev)
+        quantize_nm(x.reshape(T, K), 64, x_mant_bits, epsilon, want_deq=False, code_bits=8, want_exp=True,
+                    codes_out=xc16[:T], exps_out=xe16[:T])
+        slabs = torch.empty((slices, 16, N), dtype=torch.float32, device=dev)
+        out = torch.empty((T, N), dtype=out_dtype, device=dev)
+        check(L.bfpq_hbfp_linear_decode(_ptr(wcodes.contiguous()), _ptr(wexps.contiguous()), _ptr(xc16), _ptr(xe16), _ptr(out),
+                                        _ptr(slabs), T, N, K, DTYPE_CODE[out_dtype], int(w_mant_bits), int(x_mant_bits), _stream(x)),
+              "bfpq_hbfp_linear_decode")
+    return out.view(tuple(x.shape[:-1]) + (N,))

@@ -565,3 +565,25 @@ def test_torch_library_ops_and_compile():
     eager = lin(x)
     compiled = torch.compile(lin, backend="aot_eager", fullgraph=True)(x)
     assert torch.equal(eager, compiled)
+
+
+@pytest.mark.parametrize("N,K,T,dname", [(64, 256, 1, "bf16"), (256, 512, 5, "bf16"), (128, 1024, 16, "f16"), (4096, 11008, 16, "bf16"), (11008, 4096, 3, "bf16"), (4096, 4096, 1, "f32")])
+def test_packed_consumer_decode_linear(N, K, T, dname):
+    """§8f next #3: out = x @ W^T from the PACKED weight with integer block dot products (int8 MFMA), against the
+    same product of the fake-quantised tensors in fp64"""
+    dt = DT[dname]
+    w = synth(N, K, dt).to(DEV)
+    x = synth(T, K, dt, 1.0, seed=9).to(DEV)
+    pw = bfp_ops.PackedBFP.quantize(w, 3, 64, N=2, M=4)
+    got = pw.linear_decode(x)
+    assert got.shape == (T, N) and got.dtype == dt
+    wq = pw.dequantize().double().cpu()
+    xq = bfp_ops.float_to_bfp_blocked(x, **cfg(mant_bits=7, block_size=64), identifier='in').double().cpu()
+    want = xq @ wq.t()
+    err = (got.double().cpu() - want).abs().max() / want.abs().max()
+    tol = {"f32": 2e-6, "bf16": 6e-3, "f16": 8e-4}[dname]          # output rounding of the dtype; the sums themselves are fp32 of exact block sums
+    assert float(err) < tol, (float(err), tol)
+    # fp32 output: only the cross-block fp32 accumulation order separates it from the fp64 reference
+    got32 = native.hbfp_linear_decode(x, pw.codes, pw.exps, 3, 7, out_dtype=torch.float32)
+    err32 = (got32.double().cpu() - want).abs().max() / want.abs().max()
+    assert float(err32) < 2e-6, float(err32)
