@@ -46,6 +46,7 @@ enum {
 int bfpq_version(void);
 /* process-wide tuning knobs (measurement aid; defaults are the measured optimum on MI355X) */
 #define BFPQ_TUNE_MAX_GRID 0       /* cap on workgroups of the streaming kernels (default 1024) */
+#define BFPQ_TUNE_GEMM_ROW_TILES 1 /* 16-row tiles per wave in bfpq_hbfp_linear_decode_tiled: 0 = choose (default), 1, 2, 4 */
 int bfpq_tune(int key, int value);
 const char* bfpq_error_string(int code);
 
@@ -168,6 +169,17 @@ int bfpq_hbfp_linear_slices(int64_t N, int64_t K);
 int bfpq_hbfp_linear_decode(const void* wcodes_dev, const int8_t* wexp_dev, const int8_t* xcodes_dev, const int8_t* xexp_dev,
                             void* out_dev, float* slabs_dev, int64_t T, int64_t N, int64_t K,
                             int out_dtype, int w_mant_bits, int x_mant_bits, void* stream);
+
+/* the same product from the MFMA-tiled weight layout (a one-time repack of the packed weight; K % 128 == 0, K >= 256):
+ *   wtiles_dev [N/16][K/128][64][16] bytes: lane l = r + 16 q of the pair p holds the 16 codes k = 16q..16q+15 of row
+ *               16*rt + r for block 2p (bytes 0-7) and block 2p+1 (bytes 8-15)
+ *   wexpt_dev  [N/16][K/128][16][2] int8: exponents of the pair's two blocks per row
+ * One launch, no workspace: each workgroup owns one or two 16-row tiles, its waves split K and are summed in slice order
+ * through LDS, so the result is reproducible. */
+int bfpq_hbfp_linear_tiled_ok(int64_t N, int64_t K);   /* 1 when the tiled layout applies to [N, K] */
+int bfpq_hbfp_linear_decode_tiled(const void* wtiles_dev, const void* wexpt_dev, const int8_t* xcodes_dev, const int8_t* xexp_dev,
+                                  void* out_dev, int64_t T, int64_t N, int64_t K,
+                                  int out_dtype, int w_mant_bits, int x_mant_bits, void* stream);
 
 /* layout of state_dev as read back by a host that wants tau / counts (all little-endian) */
 typedef struct bfpq_select_state {

@@ -256,6 +256,11 @@ class PackedBFP:
         the activation is quantized to HBFP(x_mant_bits + 1) block 64 and every block's dot product is an exact
         integer sum on the int8 matrix cores (native.hbfp_linear_decode)."""
         assert self.code_bits == 4 and self.block_size == 64 and len(self.shape) == 2
+        N, K = self.shape
+        if N % 16 == 0 and K % 128 == 0 and K >= 256:                  # MFMA-tiled copy of the weight, built once
+            if getattr(self, "_tiles", None) is None:
+                self._tiles = native.mfma_tiles(self.codes, self.exps)
+            return native.hbfp_linear_decode_tiled(x, self._tiles[0], self._tiles[1], N, self.mant_bits, x_mant_bits, epsilon)
         return native.hbfp_linear_decode(x, self.codes, self.exps, self.mant_bits, x_mant_bits, epsilon)
 
     def save(self, path):

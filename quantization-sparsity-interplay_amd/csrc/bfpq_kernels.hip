@@ -24,6 +24,8 @@
 
 using namespace bfpq;
 
+extern "C" __attribute__((visibility("hidden"))) int bfpq_g_gemm_rt;   // bfpq_gemm.hip
+
 namespace {
 
 #ifndef BFPQ_MAXGRID
@@ -1185,6 +1187,7 @@ int bfpq_version(void) { return BFPQ_VERSION; }
 int bfpq_tune(int key, int value)
 {
     if (key == BFPQ_TUNE_MAX_GRID && value >= 1 && value <= 65535) { g_max_grid = value; return 0; }
+    if (key == BFPQ_TUNE_GEMM_ROW_TILES && (value == 0 || value == 1 || value == 2 || value == 4)) { bfpq_g_gemm_rt = value; return 0; }
     return BFPQ_E_ARG;
 }
 

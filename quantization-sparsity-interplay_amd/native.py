@@ -83,16 +83,18 @@ def load_library():
         L.bfpq_dequantize.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, i32, vp]
         L.bfpq_hbfp_linear_slices.argtypes = [i64, i64]
         L.bfpq_hbfp_linear_decode.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
+        L.bfpq_hbfp_linear_tiled_ok.argtypes = [i64, i64]
+        L.bfpq_hbfp_linear_decode_tiled.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
         for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
                      "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan", "bfpq_tie_count",
                      "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize", "bfpq_hbfp_linear_slices",
-                     "bfpq_hbfp_linear_decode"):
+                     "bfpq_hbfp_linear_decode", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled"):
             getattr(L, name).restype = i32
         _lib = L
         return _lib
 
 
-EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host",
+EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
                     "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan",
                     "bfpq_tie_count", "bfpq_threshold_apply", "bfpq_quantize_threshold")
@@ -368,6 +370,38 @@ def is_fused(t, block_size, N=0, M=0):
     """would quantize_nm take the single-pass kernel for this (contiguous) tensor?"""
     rows, cols = rows_cols(t)
     return bool(load_library().bfpq_is_fused(rows, cols, DTYPE_CODE[t.dtype], int(block_size), int(N), int(M))) and t.data_ptr() % 16 == 0
+
+
+def mfma_tiles(wcodes, wexps):
+    """one-time repack of a packed HBFP4 weight (codes [N, K/2] uint8, exps [N, K/64] int8, block 64) into the layout
+    bfpq_hbfp_linear_decode_tiled reads: a pure permutation, done with torch views"""
+    N, K = wexps.shape[0], wexps.shape[1] * 64
+    assert N % 16 == 0 and K % 128 == 0
+    t = wcodes.view(N // 16, 16, K // 128, 2, 4, 8).permute(0, 2, 4, 1, 3, 5).contiguous().view(N // 16, K // 128, 64, 16)
+    e = wexps.view(N // 16, 16, K // 128, 2).permute(0, 2, 1, 3).contiguous()
+    return t, e
+
+
+def hbfp_linear_decode_tiled(x, wtiles, wexpt, N, w_mant_bits, x_mant_bits=7, epsilon=1e-8, out_dtype=None):
+    """hbfp_linear_decode on the MFMA-tiled weight (see mfma_tiles)"""
+    require_device_tensor(x)
+    L = load_library()
+    K = x.shape[-1]
+    T = x.numel() // K
+    if T < 1 or T > 16 or not L.bfpq_hbfp_linear_tiled_ok(N, K):
+        raise ValueError(f"hbfp_linear_decode_tiled needs 1..16 tokens, N % 16 == 0, K % 128 == 0 and K >= 256 (got T={T}, N={N}, K={K})")
+    dev = x.device
+    out_dtype = out_dtype or x.dtype
+    with torch.cuda.device(dev):
+        xc16 = torch.empty((16, K), dtype=torch.int8, device=dev)
+        xe16 = torch.empty((16, K // 64), dtype=torch.int8, device=dev)
+        quantize_nm(x.reshape(T, K), 64, x_mant_bits, epsilon, want_deq=False, code_bits=8, want_exp=True,
+                    codes_out=xc16[:T], exps_out=xe16[:T])
+        out = torch.empty((T, N), dtype=out_dtype, device=dev)
+        check(L.bfpq_hbfp_linear_decode_tiled(_ptr(wtiles), _ptr(wexpt), _ptr(xc16), _ptr(xe16), _ptr(out), T, N, K,
+                                              DTYPE_CODE[out_dtype], int(w_mant_bits), int(x_mant_bits), _stream(x)),
+              "bfpq_hbfp_linear_decode_tiled")
+    return out.view(tuple(x.shape[:-1]) + (N,))
 
 
 def hbfp_linear_decode(x, wcodes, wexps, w_mant_bits, x_mant_bits=7, epsilon=1e-8, out_dtype=None):

@@ -567,7 +567,8 @@ def test_torch_library_ops_and_compile():
     assert torch.equal(eager, compiled)
 
 
-@pytest.mark.parametrize("N,K,T,dname", [(64, 256, 1, "bf16"), (256, 512, 5, "bf16"), (128, 1024, 16, "f16"), (4096, 11008, 16, "bf16"), (11008, 4096, 3, "bf16"), (4096, 4096, 1, "f32")])
+@pytest.mark.parametrize("N,K,T,dname", [(64, 256, 1, "bf16"), (256, 512, 5, "bf16"), (128, 1024, 16, "f16"), (4096, 11008, 16, "bf16"), (11008, 4096, 3, "bf16"), (4096, 4096, 1, "f32"),
+                                           (11008, 4096, 16, "bf16"), (8192, 512, 9, "f16"), (4096, 384, 16, "f32")])
 def test_packed_consumer_decode_linear(N, K, T, dname):
     """§8f next #3: out = x @ W^T from the PACKED weight with integer block dot products (int8 MFMA), against the
     same product of the fake-quantised tensors in fp64"""
@@ -584,6 +585,19 @@ def test_packed_consumer_decode_linear(N, K, T, dname):
     tol = {"f32": 2e-6, "bf16": 6e-3, "f16": 8e-4}[dname]          # output rounding of the dtype; the sums themselves are fp32 of exact block sums
     assert float(err) < tol, (float(err), tol)
     # fp32 output: only the cross-block fp32 accumulation order separates it from the fp64 reference
-    got32 = native.hbfp_linear_decode(x, pw.codes, pw.exps, 3, 7, out_dtype=torch.float32)
-    err32 = (got32.double().cpu() - want).abs().max() / want.abs().max()
-    assert float(err32) < 2e-6, float(err32)
+    if K % 256 == 0:
+        got32 = native.hbfp_linear_decode(x, pw.codes, pw.exps, 3, 7, out_dtype=torch.float32)
+        err32 = (got32.double().cpu() - want).abs().max() / want.abs().max()
+        assert float(err32) < 2e-6, float(err32)
+    if K % 128 == 0:                                                # the MFMA-tiled weight layout: same sums, other slice order
+        tiles, expt = native.mfma_tiles(pw.codes, pw.exps)
+        got32t = native.hbfp_linear_decode_tiled(x, tiles, expt, N, 3, 7, out_dtype=torch.float32)
+        err32t = (got32t.double().cpu() - want).abs().max() / want.abs().max()
+        assert float(err32t) < 2e-6, float(err32t)
+        try:                                                        # every tiles-per-wave variant gives the same sums
+            for rt in (1, 2, 4):
+                native.load_library().bfpq_tune(1, rt)
+                g = native.hbfp_linear_decode_tiled(x, tiles, expt, N, 3, 7, out_dtype=torch.float32)
+                assert torch.equal(g, got32t) or float((g.double().cpu() - want).abs().max() / want.abs().max()) < 2e-6, rt
+        finally:
+            native.load_library().bfpq_tune(1, 0)
