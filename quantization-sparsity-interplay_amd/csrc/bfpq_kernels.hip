@@ -512,26 +512,41 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
     // Sweep: item = sweep * stride + global thread id.  Loads run two sweeps ahead of the item being
     // processed (index clamped to the last item, never conditional).
     const int64_t last = a.n_items - 1;
-    auto fetch = [&](int64_t i) __attribute__((always_inline)) { return stream_load(src + (i < last ? i : last)); };
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    auto fetch = [&](int64_t i) __attribute__((always_inline)) {
+        return __builtin_nontemporal_load(reinterpret_cast<const u4v*>(src + (i < last ? i : last)));
+    };
+    auto u4 = [](const u4v v) __attribute__((always_inline)) { return make_uint4(v.x, v.y, v.z, v.w); };
     const int64_t full = a.n_items / stride;                               // sweeps in which every thread has an item
     int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    uint4 c0 = fetch(item);
+    u4v c0 = fetch(item);
+    // One more memory op behind the first load, result unused.  At the loop top the back edge arrives with [load, store]
+    // outstanding and the entry edge with [load] only; one s_waitcnt immediate must serve both edges, so the compiler
+    // emitted vmcnt(0) and every wave waited for its just-issued store once per iteration.  With [load, dummy] on the
+    // entry edge both edges need vmcnt(1) and the store stays in flight across the loop top (A/B: 32.5 -> 31.95 us).
+    // NB the scheduler still hoists the tile's first v_perm above the next prefetch, so a wave has ONE load in flight,
+    // issued when the previous arrives; pinning the prefetch in front of that wait (two loads in flight) measured
+    // SLOWER (33.25 us) -- like every other variant with more reads in flight per wave on this part.
+    asm volatile("" ::: "memory");                                         // (pins the dummy between the first load and the loop)
+    const uint32_t dummy = *reinterpret_cast<const uint32_t*>(src);
+    asm volatile("" ::: "memory");
     int64_t sweep = 0;
     // main loop: load one sweep ahead; unrolled by two so that the two register sets alternate by NAME
     // (copying a register that a load in flight will write forces vmcnt(0)); with nothing conditional in
     // the body the waits are counted and the previous store stays in flight across the loop top
     for (; sweep + 2 <= full; sweep += 2, item += 2 * stride) {
-        const uint4 c1 = fetch(item + stride);
-        body(std::false_type{}, item, c0);
+        const u4v c1 = fetch(item + stride);
+        body(std::false_type{}, item, u4(c0));
         c0 = fetch(item + 2 * stride);
-        body(std::false_type{}, item + stride, c1);
+        body(std::false_type{}, item + stride, u4(c1));
     }
     // remaining full sweep (0..1) and the ragged last one: guarded, rolled (block-uniform trip count)
     for (; item < n_round; item += stride) {
-        const uint4 c1 = fetch(item + stride);
-        body(std::true_type{}, item, c0);
+        const u4v c1 = fetch(item + stride);
+        body(std::true_type{}, item, u4(c0));
         c0 = c1;
     }
+    asm volatile("" : : "v"(dummy));                                       // the dummy's only "use": after all the work
 }
 
 // ---------------------------------------------------------------------------------------------
