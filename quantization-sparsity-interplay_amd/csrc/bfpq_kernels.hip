@@ -553,6 +553,31 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
 // k_nm_rows: one thread per N:M group, general M, ragged rows (tail group padded with zeros as
 // F.pad does, bfp_ops.py:79-82).  codes (optional) are zeroed where an element is pruned.
 // ---------------------------------------------------------------------------------------------
+// Prune mask of one group whose (key << 8 | index) pairs sit in `view`.  Which elements the reference's topk drops is
+// only a question of ITS tie order when equal magnitudes straddle the cut; otherwise "the M-N smallest" is unambiguous.
+// So: count, for every element, the keys below it and the keys equal to it (M^2 uniform LDS reads, no branches); an
+// element with less + equal <= P is certainly pruned, one with less >= P certainly kept.  Only a group that has an
+// element in between replays libstdc++'s nth_element (nm_prune_mask) -- rare on real-valued weights, common on inputs
+// that are already quantized.
+__device__ __forceinline__ uint64_t nm_prune_mask_counted(KvView& view, int N, int M)
+{
+    const int P = M - N;
+    uint64_t prune = 0;
+    bool ambiguous = false;
+    for (int i = 0; i < M; i++) {
+        const uint64_t ki = view.get(i) >> 8;
+        int less = 0, eq = 0;
+        for (int j = 0; j < M; j++) {
+            const uint64_t kj = view.get(j) >> 8;
+            less += kj < ki;
+            eq += kj == ki;
+        }
+        if (less + eq <= P) prune |= 1ull << i;
+        else if (less < P) ambiguous = true;
+    }
+    return ambiguous ? nm_prune_mask(view, N, M) : prune;
+}
+
 template <int DT>
 __global__ void __launch_bounds__(128) k_nm_rows(const void* in, void* out, void* codes, int code_bits,
                                                  int64_t rows, int64_t cols, int N, int M)
@@ -573,6 +598,53 @@ __global__ void __launch_bounds__(128) k_nm_rows(const void* in, void* out, void
         // whole groups that are 16-byte multiples at 16-byte aligned addresses move as vectors
         const bool vec_io = !codes && (M % EPV) == 0 && (cols % M) == 0 &&
                             ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+        if (vec_io && M == 8) {
+            // the common general case (N:8) entirely in registers: 28 pair comparisons give every element its count of
+            // smaller and of equal keys; LDS and the nth_element replay only for a group whose ties straddle the cut
+            constexpr int Q = 8 / EPV;                                      // 16-byte vectors per group (1 or 2)
+            uint32_t d[Q][4], key[8];
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+                const uint4 v = reinterpret_cast<const uint4*>(src + base)[q];
+                d[q][0] = v.x; d[q][1] = v.y; d[q][2] = v.z; d[q][3] = v.w;
+#pragma unroll
+                for (int e = 0; e < EPV; e++)
+                    key[q * EPV + e] = mag_key<DT>(sizeof(raw_t) == 4 ? d[q][e] : ((d[q][e >> 1] >> (16 * (e & 1))) & 0xffffu));
+            }
+            int less[8] = {0, 0, 0, 0, 0, 0, 0, 0}, eq[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+#pragma unroll
+                for (int j = i + 1; j < 8; j++) {
+                    const int lt = key[i] < key[j], e = key[i] == key[j];
+                    less[j] += lt; less[i] += 1 - lt - e; eq[i] += e; eq[j] += e;
+                }
+            const int P = 8 - N;
+            uint32_t prune = 0;
+            bool ambiguous = false;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (less[i] + eq[i] <= P) prune |= 1u << i;
+                else if (less[i] < P) ambiguous = true;
+            }
+            if (ambiguous) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) view.set(i, ((uint64_t)key[i] << 8) | (uint64_t)i);
+                prune = (uint32_t)nm_prune_mask(view, N, M);
+            }
+#pragma unroll
+            for (int q = 0; q < Q; q++) {
+#pragma unroll
+                for (int e = 0; e < EPV; e++) {
+                    if ((prune >> (q * EPV + e)) & 1u) {
+                        if (sizeof(raw_t) == 4) d[q][e] = 0u;
+                        else d[q][e >> 1] &= (e & 1) ? 0x0000ffffu : 0xffff0000u;
+                    }
+                }
+                reinterpret_cast<uint4*>(dst + base)[q] = make_uint4(d[q][0], d[q][1], d[q][2], d[q][3]);
+            }
+            continue;
+        }
         if (vec_io) {
             for (int q = 0; q < M / EPV; q++) {
                 const uint4 v = reinterpret_cast<const uint4*>(src + base)[q];
@@ -583,7 +655,7 @@ __global__ void __launch_bounds__(128) k_nm_rows(const void* in, void* out, void
                     view.set(q * EPV + e, ((uint64_t)mag_key<DT>(r) << 8) | (uint64_t)(q * EPV + e));
                 }
             }
-            const uint64_t prune = nm_prune_mask(view, N, M);
+            const uint64_t prune = nm_prune_mask_counted(view, N, M);
             for (int q = 0; q < M / EPV; q++) {
                 uint4 v = reinterpret_cast<const uint4*>(src + base)[q];
                 uint32_t d[4] = {v.x, v.y, v.z, v.w};
@@ -602,7 +674,7 @@ __global__ void __launch_bounds__(128) k_nm_rows(const void* in, void* out, void
             const uint32_t key = i < n ? mag_key<DT>((uint32_t)src[base + i]) : 0u;
             view.set(i, ((uint64_t)key << 8) | (uint64_t)i);
         }
-        const uint64_t prune = nm_prune_mask(view, N, M);
+        const uint64_t prune = nm_prune_mask_counted(view, N, M);
         for (int i = 0; i < n; i++) {
             const bool p = (prune >> i) & 1ull;
             dst[base + i] = p ? (raw_t)0 : src[base + i];
@@ -717,14 +789,28 @@ __global__ void __launch_bounds__(kThreads) k_quant_rows_vec(const void* in, voi
 #pragma unroll
         for (int e = 0; e < VEC; e++) { const uint32_t k = raw[e] & T::ABS; mx = k > mx ? k : mx; }
         for (int o = 1; o < GP; o <<= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)mx, o, 64); mx = other > mx ? other : mx; }
-        const BlockScale bs = block_scale<DT>(mx, mant_bits, eps_dt, s_win);
-        if (!valid) continue;
+        // same split as the flat kernel: exact power-of-two arithmetic unless some block of the wave is unusual
+        // (zero / non-finite max, scale outside the normal range, mantissa wider than the dtype) or rounding is stochastic
+        const FastScale fs = fast_scale<DT>(mx, mant_bits, eps_dt, s_win);
         float y[VEC], code[VEC];
+        int8_t e_sat;
+        if (__builtin_expect(__any(stoch || !fs.ok), 0)) {
+            const BlockScale bs = block_scale<DT>(mx, mant_bits, eps_dt, s_win);
+            e_sat = sat_exp(bs);
 #pragma unroll
-        for (int e = 0; e < VEC; e++) {
-            const float dither = stoch ? uniform24(seed, (uint64_t)item * VEC + e) - 0.5f : 0.f;
-            y[e] = quant_elem<DT>(raw_to_f32<DT>(raw[e]), bs, stoch, dither, &code[e]);
+            for (int e = 0; e < VEC; e++) {
+                const float dither = stoch ? uniform24(seed, (uint64_t)item * VEC + e) - 0.5f : 0.f;
+                y[e] = quant_elem<DT>(raw_to_f32<DT>(raw[e]), bs, stoch, dither, &code[e]);
+            }
+        } else {
+            e_sat = (int8_t)(fs.e < -127 ? -127 : (fs.e > 127 ? 127 : fs.e));
+#pragma unroll
+            for (int e = 0; e < VEC; e++) {
+                code[e] = __builtin_amdgcn_fmed3f(rintf(raw_to_f32<DT>(raw[e]) * fs.inv), -fs.qmax, fs.qmax);
+                y[e] = code[e] * fs.interval;
+            }
         }
+        if (!valid) continue;
         if (out_deq) {
             uint32_t o[VEC];
 #pragma unroll
@@ -752,7 +838,7 @@ __global__ void __launch_bounds__(kThreads) k_quant_rows_vec(const void* in, voi
                 for (int e = 0; e < VEC; e++) reinterpret_cast<int16_t*>(out_codes)[item * VEC + e] = (int16_t)c[e];
             }
         }
-        if (out_exp && j == 0) out_exp[b] = sat_exp(bs);
+        if (out_exp && j == 0) out_exp[b] = e_sat;
     }
 }
 

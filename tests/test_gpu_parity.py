@@ -462,9 +462,13 @@ def test_g9_int_format_golden():
 
 
 def test_int_format_oracle_at_model_shapes():
-    for rows, cols, dname, ident in ((4096, 4096, "bf16", 'w'), (11008, 4096, "f16", 'w'), (1024, 20000, "f32", 'w'), (8 * 197, 1024, "f32", 'in')):
+    for rows, cols, dname, ident in ((4096, 4096, "bf16", 'w'), (11008, 4096, "f16", 'w'), (1024, 20000, "f32", 'w'), (8 * 197, 1024, "f32", 'in'),
+                                     (520, 11008, "bf16", 'w'), (130, 16384, "f16", 'w'), (300, 6144, "f32", 'w'), (70, 3000, "bf16", 'w'),
+                                     (33, 1024, "f32", 'w')):          # the register-resident row kernel, 2..8 items per thread
         dt = DT[dname]
         xc = synth(rows, cols, dt, 0.05 if ident == 'w' else 1.0)
+        if rows == 70:
+            xc[3, 17] = float('nan'); xc[5] = 0                       # a NaN row and an all-zero row
         c = cfg(sparsity_num_format='int', mant_bits=8, block_size=32)
         got = bfp_ops.float_to_bfp_blocked(xc.to(DEV), **c, identifier=ident)
         want = O.float_to_bfp_blocked(xc, **c, identifier=ident)
