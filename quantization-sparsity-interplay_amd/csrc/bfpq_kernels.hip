@@ -89,7 +89,9 @@ __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) { uint32_
 __device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_max_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ uint32_t pk_mad_i16(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ uint32_t pk_add_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_add_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 // same with the constant operand in an SGPR (one scalar operand per VALU instruction is allowed)
+__device__ __forceinline__ uint32_t pk_ashr_i16_s(uint32_t a, uint32_t sh) { uint32_t d; asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(d) : "s"(sh), "v"(a)); return d; }
 __device__ __forceinline__ uint32_t pk_max_i16_s(uint32_t a, uint32_t k) { uint32_t d; asm("v_pk_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k)); return d; }
 __device__ __forceinline__ uint32_t pk_min_i16_s(uint32_t a, uint32_t k) { uint32_t d; asm("v_pk_min_i16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k)); return d; }
 __device__ __forceinline__ uint32_t pk_mad_i16_s(uint32_t a, uint32_t k, uint32_t c) { uint32_t d; asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c)); return d; }
@@ -280,6 +282,7 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
     __shared__ uint8_t s_win[512];
     __shared__ uint2 s_mask[NM == 4 && VEC == 8 ? 736 : 1];      // 16-bit dtypes: AND masks for the two dwords of a group
     __shared__ uint8_t s_keep[NM == 4 && VEC == 4 ? 736 : 1];    // fp32: 4-bit keep mask
+    __shared__ uint64_t s_kv[NM == 8 ? 8 * kThreads : 1];        // N:8: column per thread for the nth_element replay (rare)
     for (int i = threadIdx.x; i < 512; i += kThreads)
         s_win[i] = (a.exp_win && i < BFPQ_EXP_WIN_ENTRIES) ? a.exp_win[i] : 0;
     if constexpr (NM == 4) {
@@ -318,6 +321,52 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
                 auto m = [](uint32_t pr) { return ((pr & 1u) ? 0u : 0xffffu) | ((pr & 2u) ? 0u : 0xffff0000u); };
                 d0 &= m(prune); d1 &= m(prune >> 2); d2 &= m(prune >> 4); d3 &= m(prune >> 6);
             }
+        } else if constexpr (NM == 8) {
+            // one lane item = one group of 8 (16-bit dtypes).  Count, per element, the smaller and the equal keys (28 pair
+            // comparisons in registers): less + equal <= P -> certainly pruned, less >= P -> certainly kept; only a group
+            // whose ties straddle the cut needs the reference's tie order (libstdc++ nth_element replay on an LDS column)
+            static_assert(VEC == 8, "N:8 in the flat kernel is for 16-bit dtypes");
+            // Packed: the item's four dwords ARE the key pairs.  c = clamp(k_i - k_j, -1, 1) for two pairs per instruction;
+            // per element S = sum_j c = 2 less + eq - 8 and A = sum_j c^2 = 8 - eq, so
+            //   pruned  <=> less + eq <= P <=> S - A <= 2P - 16,      certainly kept <=> less >= P <=> S + A >= 2P
+            const uint32_t absm = T::ABS | (T::ABS << 16), nanc = (T::INF + 1u) | ((T::INF + 1u) << 16);
+            uint32_t D[4] = {d0, d1, d2, d3}, K[4], Kr[4], S[4] = {0, 0, 0, 0}, A[4] = {0, 0, 0, 0};
+            auto rot = [](uint32_t x) { return __builtin_amdgcn_alignbit(x, x, 16); };
+            auto c3 = [&](uint32_t x, uint32_t y) { return pk_min_i16_s(pk_max_i16_s(pk_sub_i16(x, y), 0xffffffffu), 0x00010001u); };
+#pragma unroll
+            for (int x = 0; x < 4; x++) { K[x] = pk_min_i16_s(D[x] & absm, nanc); Kr[x] = rot(K[x]); }
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const uint32_t c = c3(K[x], Kr[x]);                       // the two elements of one dword against each other
+                S[x] = pk_add_i16(S[x], c); A[x] = pk_mad_i16(c, c, A[x]);
+#pragma unroll
+                for (int y = x + 1; y < 4; y++) {
+                    const uint32_t c1 = c3(K[x], K[y]);                   // (x0 - y0, x1 - y1)
+                    S[x] = pk_add_i16(S[x], c1); A[x] = pk_mad_i16(c1, c1, A[x]);
+                    S[y] = pk_sub_i16(S[y], c1); A[y] = pk_mad_i16(c1, c1, A[y]);
+                    const uint32_t c2 = c3(K[x], Kr[y]), c2r = rot(c2);   // (x0 - y1, x1 - y0); rotated: indexed by y's lanes
+                    S[x] = pk_add_i16(S[x], c2); A[x] = pk_mad_i16(c2, c2, A[x]);
+                    S[y] = pk_sub_i16(S[y], c2r); A[y] = pk_mad_i16(c2r, c2r, A[y]);
+                }
+            }
+            const int P = 8 - a.N;
+            const uint32_t cp = (uint32_t)((2 * P - 16) & 0xffff) * 0x10001u, pp = (uint32_t)(2 * P) * 0x10001u;
+            uint32_t keep[4], amb = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                keep[x] = pk_ashr_i16_s(pk_sub_i16(pk_add_i16(A[x], cp), S[x]), 0x000f000fu);        // 0xffff where S - A > 2P - 16
+                amb |= keep[x] & pk_ashr_i16_s(pk_sub_i16(pk_add_i16(S[x], A[x]), pp), 0x000f000fu);  // ... and S + A < 2P
+            }
+            if (amb) {                                                    // ties straddle the cut: the reference's tie order decides
+                KvView view{s_kv + threadIdx.x, kThreads};
+#pragma unroll
+                for (int i = 0; i < 8; i++) view.set(i, ((uint64_t)((K[i >> 1] >> (16 * (i & 1))) & 0xffffu) << 8) | (uint64_t)i);
+                const uint32_t prune = (uint32_t)nm_prune_mask(view, a.N, 8);
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                    keep[x] = (((prune >> (2 * x)) & 1u) ? 0u : 0xffffu) | (((prune >> (2 * x + 1)) & 1u) ? 0u : 0xffff0000u);
+            }
+            d0 &= keep[0]; d1 &= keep[1]; d2 &= keep[2]; d3 &= keep[3];
         } else if constexpr (NM == 4 && VEC == 8) {
             // A_i = (group0.elem_i | group1.elem_i << 16): both groups go through one packed instruction
             const uint32_t absm = T::ABS | (T::ABS << 16), nanc = (T::INF + 1u) | ((T::INF + 1u) << 16);
@@ -1204,9 +1253,25 @@ int launch_fused_threshold(const FusedArgs& a, hipStream_t s)
     return (int)hipGetLastError();
 }
 
+// N:8 (16-bit dtypes): few instantiations -- lane groups 8 (block 64) or run-time
+template <int DT, bool SFIRST, bool STOCH>
+int launch_fused_nm8(const FusedArgs& a, hipStream_t s)
+{
+    if constexpr (Traits<DT>::VEC == 8) {
+        const dim3 grid(grid_for(a.n_items)), block(kThreads);
+        const bool deq_only = a.out_deq && !a.out_codes && !a.out_exp;
+        if constexpr (STOCH) hipLaunchKernelGGL((k_fused_flat<DT, 8, SFIRST, true, -1, false>), grid, block, 0, s, a);
+        else if (deq_only && a.lpb == 8) hipLaunchKernelGGL((k_fused_flat<DT, 8, SFIRST, false, 8, true>), grid, block, 0, s, a);
+        else if (deq_only) hipLaunchKernelGGL((k_fused_flat<DT, 8, SFIRST, false, -1, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_fused_flat<DT, 8, SFIRST, false, -1, false>), grid, block, 0, s, a);
+        return (int)hipGetLastError();
+    } else return BFPQ_E_UNSUPPORTED;
+}
+
 template <int DT, bool STOCH>
 int launch_fused_s(const FusedArgs& a, int M, bool sfirst, hipStream_t s)
 {
+    if (M == 8) return sfirst ? launch_fused_nm8<DT, true, STOCH>(a, s) : launch_fused_nm8<DT, false, STOCH>(a, s);
     if (M == 0) return launch_fused_l<DT, 0, true, STOCH>(a, s);
     if (M == 2) return sfirst ? launch_fused_l<DT, 2, true, STOCH>(a, s) : launch_fused_l<DT, 2, false, STOCH>(a, s);
     return sfirst ? launch_fused_l<DT, 4, true, STOCH>(a, s) : launch_fused_l<DT, 4, false, STOCH>(a, s);
@@ -1268,7 +1333,7 @@ bool fused_shape_ok(int64_t rows, int64_t cols, int dtype, int block_size, int N
     const int vec = dtype_vec(dtype);
     const int64_t numel = rows * cols;
     if (numel == 0 || numel % vec != 0) return false;
-    if (!(M == 0 || M == 2 || M == 4)) return false;
+    if (!(M == 0 || M == 2 || M == 4 || (M == 8 && vec == 8))) return false;   // N:8 = one 16-byte item of a 16-bit dtype
     if (M != 0 && cols % M != 0) return false;
     if (block_size == 0) return M != 0;                              // sparsify only
     if (cols % block_size != 0 || block_size % vec != 0) return false;

@@ -306,6 +306,38 @@ def test_packed_roundtrip(dname, m, blk, code_bits):
         assert torch.equal(codes2, codes) and torch.equal(exps2, exps)
 
 
+@pytest.mark.parametrize("dname", ["bf16", "f16"])
+def test_nm8_in_the_flat_kernel(dname):
+    """N:8 on 16-bit dtypes runs inside the fused kernel (one lane item = one group): counted decision in registers,
+    nth_element replay only when ties straddle the cut.  Real-valued rows (no straddling ties), coarse-grid rows (ties
+    everywhere -> the replay), both orders, drop-in and packed outputs, sparsify-only, vs the oracle."""
+    dt = DT[dname]
+    assert native.is_fused(torch.empty(64, 1024, dtype=dt, device=DEV), 64, 4, 8)
+    real = synth(96, 1024, dt)
+    coarse = (synth(96, 1024, dt, 1.0, seed=5).float() * 2).round().div(2).to(dt)        # ~9 distinct magnitudes
+    for xc, tag in ((real, "real"), (coarse, "coarse")):
+        for N in (1, 2, 4, 5, 7):
+            for first in ('s', 'q'):
+                for blk, m in ((64, 3), (32, 7)):
+                    c = cfg(mant_bits=m, block_size=blk, w_sparsity=True, N=N, M=8, first=first)
+                    got = bfp_ops.float_to_bfp_blocked(xc.to(DEV), **c, identifier='w')
+                    want = O.float_to_bfp_blocked(xc, **c, identifier='w')
+                    assert_bits_equal(bits(got), bits(want), dt, f"{tag} {N}:8 first={first} b{blk} m{m}")
+            got = bfp_ops._structured_N_M_sparsity(xc.to(DEV), DEV, N, 8)
+            assert_bits_equal(bits(got), bits(O.structured_N_M_sparsity(xc, N, 8).view(xc.shape)), dt, f"{tag} {N}:8 sparsify only")
+        # packed output (codes + exponents) of the same kernel
+        codes, exps, deq = bfp_ops.float_to_bfp_packed(xc.to(DEV), 3, 64, N=4, M=8, first='s', code_bits=4, with_dequant=True)
+        want = O.float_to_bfp_blocked(xc, **cfg(mant_bits=3, block_size=64, w_sparsity=True, N=4, M=8), identifier='w')
+        assert_bits_equal(bits(deq), bits(want), dt, f"{tag} packed deq")
+        back = bfp_ops.PackedBFP(codes, exps, xc.shape, dt, 3, 64, 4).dequantize()
+        assert torch.equal(back.cpu().double(), want.double()), f"{tag} packed roundtrip"      # (a code has no -0)
+    # the fp32 tensor still takes the general kernel (a group spans two lane items) and must agree as well
+    x32 = synth(64, 512, torch.float32)
+    c = cfg(mant_bits=3, block_size=64, w_sparsity=True, N=4, M=8)
+    assert_bits_equal(bits(bfp_ops.float_to_bfp_blocked(x32.to(DEV), **c, identifier='w')),
+                      bits(O.float_to_bfp_blocked(x32, **c, identifier='w')), torch.float32, "f32 4:8")
+
+
 def test_packed_general_path_matches_fused():
     """same tensor through the ragged-row kernels, forced by a storage offset that breaks 16-B alignment"""
     xc = synth(64, 512, torch.bfloat16)
