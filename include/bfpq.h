@@ -42,6 +42,7 @@ enum {
  * once per device; keeping them caller-owned keeps the library stateless) */
 #define BFPQ_EXP_WIN_ENTRIES 320   /* uint8 per unbiased exponent k in [-160, 160)              */
 #define BFPQ_NM4_LUT_ENTRIES 729   /* uint8 keep-mask per 3^6 pairwise-comparison signature     */
+#define BFPQ_NM8_LUT_ENTRIES (1 << 24) /* uint8 prune-mask per (number of smaller keys)^8 vector, 3 bits each */
 
 int bfpq_version(void);
 /* process-wide tuning knobs (measurement aid; defaults are the measured optimum on MI355X) */
@@ -60,6 +61,11 @@ const char* bfpq_error_string(int code);
  * used by _structured_N_M_sparsity (bfp_ops.py:85). */
 int bfpq_exp_window_host(int dtype, uint8_t* table_host /* [BFPQ_EXP_WIN_ENTRIES] */);
 int bfpq_nm4_lut_host(int N, uint8_t* lut_host /* [BFPQ_NM4_LUT_ENTRIES] */);
+/* bfpq_nm8_lut_host: PRUNE mask (bit i set = element i zeroed) of one group of 8 for "keep N of 8", indexed by
+ * sum_i less_i << (3 i) with less_i = number of keys strictly smaller than key i (this vector identifies the weak
+ * ordering of the group, which is all std::nth_element's behaviour depends on).  16 MiB, optional: pass it as nm4_lut_dev
+ * when M == 8; with NULL the kernel replays nth_element for the groups whose ties straddle the cut (slower, same result). */
+int bfpq_nm8_lut_host(int N, uint8_t* lut_host /* [BFPQ_NM8_LUT_ENTRIES] */);
 /* host restatement of the N:M selection for one group (any 1 <= N <= M <= 64); keys are
  * non-negative magnitudes compared as unsigned integers. Returns the 64-bit PRUNE mask. Used by the
  * host-logic tests and to build the LUT above. */
@@ -81,8 +87,8 @@ uint64_t bfpq_nm_prune_mask_host(const uint32_t* keys, int N, int M);
  *   out_exp_dev   int8 [rows, ceil(cols/block)] shared exponent e (value = code * 2^(e-mant_bits));
  *                 saturated to [-127, 127]; -128 marks a block the reference turns into NaN
  * Any shape, block size and 1 <= N <= M <= 64 is accepted; the single-pass fused kernel is used
- * when cols % block == 0, block is 16 bytes x a power of two <= 64 lanes, and M in {0, 2, 4}
- * divides the block; otherwise the work is split into a sparsify and a quantize launch through
+ * when cols % block == 0, block is 16 bytes x a power of two <= 64 lanes, and M in {0, 2, 4} (or 8 on a
+ * 16-bit dtype) divides the block; otherwise the work is split into a sparsify and a quantize launch through
  * scratch_dev (rows*cols elements of dtype, may be NULL when the fused kernel applies).
  * stoch_seed == 0 -> round-half-even; otherwise stochastic rounding (uniform dither in
  * [-0.5, 0.5) from a counter-based generator keyed by (seed, element index), bfp_ops.py:21-23). */

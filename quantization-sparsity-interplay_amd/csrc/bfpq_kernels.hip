@@ -358,10 +358,24 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
                 amb |= keep[x] & pk_ashr_i16_s(pk_sub_i16(pk_add_i16(S[x], A[x]), pp), 0x000f000fu);  // ... and S + A < 2P
             }
             if (amb) {                                                    // ties straddle the cut: the reference's tie order decides
-                KvView view{s_kv + threadIdx.x, kThreads};
+                uint32_t prune;
+                if (a.nm_lut) {
+                    // what nth_element does depends only on the weak ordering of the 8 keys, i.e. on the vector of
+                    // "number of smaller keys" less_i = (S_i + A_i) / 2: 8 x 3 bits index a host-built 16 MiB table
+                    // (bfpq_nm8_lut_host) that only these few lanes touch
+                    uint32_t idx = 0;
 #pragma unroll
-                for (int i = 0; i < 8; i++) view.set(i, ((uint64_t)((K[i >> 1] >> (16 * (i & 1))) & 0xffffu) << 8) | (uint64_t)i);
-                const uint32_t prune = (uint32_t)nm_prune_mask(view, a.N, 8);
+                    for (int x = 0; x < 4; x++) {
+                        const uint32_t l2 = pk_add_i16(S[x], A[x]);       // 2 * less per half, 0..14
+                        idx |= (((l2 >> 1) & 7u) | (((l2 >> 17) & 7u) << 3)) << (6 * x);
+                    }
+                    prune = a.nm_lut[idx];
+                } else {
+                    KvView view{s_kv + threadIdx.x, kThreads};
+#pragma unroll
+                    for (int i = 0; i < 8; i++) view.set(i, ((uint64_t)((K[i >> 1] >> (16 * (i & 1))) & 0xffffu) << 8) | (uint64_t)i);
+                    prune = (uint32_t)nm_prune_mask(view, a.N, 8);
+                }
 #pragma unroll
                 for (int x = 0; x < 4; x++)
                     keep[x] = (((prune >> (2 * x)) & 1u) ? 0u : 0xffffu) | (((prune >> (2 * x + 1)) & 1u) ? 0u : 0xffff0000u);
@@ -629,7 +643,7 @@ __device__ __forceinline__ uint64_t nm_prune_mask_counted(KvView& view, int N, i
 
 template <int DT>
 __global__ void __launch_bounds__(128) k_nm_rows(const void* in, void* out, void* codes, int code_bits,
-                                                 int64_t rows, int64_t cols, int N, int M)
+                                                 int64_t rows, int64_t cols, int N, int M, const uint8_t* lut8)
 {
     using raw_t = typename Traits<DT>::raw_t;
     extern __shared__ uint64_t s_kv[];                    // [M][blockDim.x]
@@ -676,7 +690,12 @@ __global__ void __launch_bounds__(128) k_nm_rows(const void* in, void* out, void
                 if (less[i] + eq[i] <= P) prune |= 1u << i;
                 else if (less[i] < P) ambiguous = true;
             }
-            if (ambiguous) {
+            if (ambiguous && lut8) {                                        // the weak ordering indexes the host-built table
+                uint32_t idx = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) idx |= (uint32_t)less[i] << (3 * i);
+                prune = lut8[idx];
+            } else if (ambiguous) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) view.set(i, ((uint64_t)key[i] << 8) | (uint64_t)i);
                 prune = (uint32_t)nm_prune_mask(view, N, M);
@@ -1283,7 +1302,7 @@ int launch_fused(const FusedArgs& a, int M, bool sfirst, hipStream_t s)
     return a.seed ? launch_fused_s<DT, true>(a, M, sfirst, s) : launch_fused_s<DT, false>(a, M, sfirst, s);
 }
 
-int launch_nm_rows(const void* in, void* out, void* codes, int code_bits, int64_t rows, int64_t cols, int dtype, int N, int M, hipStream_t s)
+int launch_nm_rows(const void* in, void* out, void* codes, int code_bits, int64_t rows, int64_t cols, int dtype, int N, int M, const uint8_t* lut8, hipStream_t s)
 {
     const int threads = 128;
     const int64_t total = rows * ((cols + M - 1) / M);
@@ -1296,9 +1315,9 @@ int launch_nm_rows(const void* in, void* out, void* codes, int code_bits, int64_
         (void)hipFuncSetAttribute((const void*)k_nm_rows<BFPQ_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute((const void*)k_nm_rows<BFPQ_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
-    if (dtype == BFPQ_F32) hipLaunchKernelGGL((k_nm_rows<BFPQ_F32>), dim3(grid), dim3(threads), lds, s, in, out, codes, code_bits, rows, cols, N, M);
-    else if (dtype == BFPQ_F16) hipLaunchKernelGGL((k_nm_rows<BFPQ_F16>), dim3(grid), dim3(threads), lds, s, in, out, codes, code_bits, rows, cols, N, M);
-    else hipLaunchKernelGGL((k_nm_rows<BFPQ_BF16>), dim3(grid), dim3(threads), lds, s, in, out, codes, code_bits, rows, cols, N, M);
+    if (dtype == BFPQ_F32) hipLaunchKernelGGL((k_nm_rows<BFPQ_F32>), dim3(grid), dim3(threads), lds, s, in, out, codes, code_bits, rows, cols, N, M, lut8);
+    else if (dtype == BFPQ_F16) hipLaunchKernelGGL((k_nm_rows<BFPQ_F16>), dim3(grid), dim3(threads), lds, s, in, out, codes, code_bits, rows, cols, N, M, lut8);
+    else hipLaunchKernelGGL((k_nm_rows<BFPQ_BF16>), dim3(grid), dim3(threads), lds, s, in, out, codes, code_bits, rows, cols, N, M, lut8);
     return (int)hipGetLastError();
 }
 
@@ -1412,6 +1431,32 @@ int bfpq_nm4_lut_host(int N, uint8_t* lut)
     return 0;
 }
 
+// every weak ordering of 8 elements (545 835 of them), generated level by level: the elements of the next level all have
+// `placed` strictly smaller elements
+static void nm8_enumerate(uint32_t remaining, int placed, uint32_t idx, uint32_t* less, int N, uint8_t* lut)
+{
+    if (!remaining) {
+        lut[idx] = (uint8_t)bfpq_nm_prune_mask_host(less, N, 8);       // keys = ranks: same ordering, same ties
+        return;
+    }
+    for (uint32_t sub = remaining; sub; sub = (sub - 1) & remaining) {
+        uint32_t id = idx;
+        int cnt = 0;
+        for (int i = 0; i < 8; i++)
+            if ((sub >> i) & 1u) { less[i] = (uint32_t)placed; id |= (uint32_t)placed << (3 * i); cnt++; }
+        nm8_enumerate(remaining ^ sub, placed + cnt, id, less, N, lut);
+    }
+}
+
+int bfpq_nm8_lut_host(int N, uint8_t* lut)
+{
+    if (!lut || N < 1 || N > 8) return BFPQ_E_ARG;
+    memset(lut, 0, BFPQ_NM8_LUT_ENTRIES);
+    uint32_t less[8];
+    nm8_enumerate(0xffu, 0, 0u, less, N, lut);
+    return 0;
+}
+
 int bfpq_is_fused(int64_t rows, int64_t cols, int dtype, int block_size, int N, int M)
 {
     if (dtype < 0 || dtype > 2) return 0;
@@ -1474,20 +1519,20 @@ int bfpq_quantize_nm(const void* in, void* out_deq, void* out_codes, int8_t* out
     };
     if (block_size == 0) {                                               // sparsify only
         if (!out_deq) return BFPQ_E_ARG;
-        return launch_nm_rows(in, out_deq, nullptr, 0, rows, cols, dtype, N, M, s);
+        return launch_nm_rows(in, out_deq, nullptr, 0, rows, cols, dtype, N, M, M == 8 ? nm4_lut : nullptr, s);
     }
     if (M == 0) return quantize_stage(in, out_deq);
     void* tmp = out_deq ? out_deq : scratch;
     if (!tmp) return BFPQ_E_ARG;
     int rc;
     if (sparsify_first) {
-        rc = launch_nm_rows(in, tmp, nullptr, 0, rows, cols, dtype, N, M, s);
+        rc = launch_nm_rows(in, tmp, nullptr, 0, rows, cols, dtype, N, M, M == 8 ? nm4_lut : nullptr, s);
         if (rc) return rc;
         return quantize_stage(tmp, out_deq);
     }
     rc = quantize_stage(in, tmp);
     if (rc) return rc;
-    return launch_nm_rows(tmp, tmp, out_codes, code_bits, rows, cols, dtype, N, M, s);
+    return launch_nm_rows(tmp, tmp, out_codes, code_bits, rows, cols, dtype, N, M, M == 8 ? nm4_lut : nullptr, s);
 }
 
 int bfpq_nm_sparsify(const void* in, void* out, int64_t rows, int64_t cols, int dtype, int N, int M,

@@ -21,6 +21,8 @@ DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
 EXP_WIN_ENTRIES = 320
 NM4_LUT_ENTRIES = 729
+NM8_LUT_ENTRIES = 1 << 24
+USE_NM8_TABLE = True               # False: N:8 groups with straddling ties replay nth_element in the kernel (tests)
 SELECT_STATE_BYTES = 64
 SELECT_HIST_BINS = 32768
 
@@ -64,6 +66,7 @@ def load_library():
         L.bfpq_error_string.argtypes = [i32]
         L.bfpq_exp_window_host.argtypes = [i32, vp]
         L.bfpq_nm4_lut_host.argtypes = [i32, vp]
+        L.bfpq_nm8_lut_host.argtypes = [i32, vp]
         L.bfpq_nm_prune_mask_host.argtypes = [vp, i32, i32]
         L.bfpq_nm_prune_mask_host.restype = u64
         L.bfpq_quantize_nm.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, dbl, i32, i32, i32, i32, u64, vp, vp, vp, vp]
@@ -85,7 +88,7 @@ def load_library():
         L.bfpq_hbfp_linear_decode.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
         L.bfpq_hbfp_linear_tiled_ok.argtypes = [i64, i64]
         L.bfpq_hbfp_linear_decode_tiled.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
-        for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
+        for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
                      "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan", "bfpq_tie_count",
                      "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize", "bfpq_hbfp_linear_slices",
                      "bfpq_hbfp_linear_decode", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled"):
@@ -94,7 +97,7 @@ def load_library():
         return _lib
 
 
-EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host",
+EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
                     "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan",
                     "bfpq_tie_count", "bfpq_threshold_apply", "bfpq_quantize_threshold")
@@ -142,6 +145,17 @@ def exp_window_dev(dtype, device):
 
 def nm4_lut_dev(N, device):
     return _device_table("lut", int(N), device, lambda: nm4_lut_host(N))
+
+
+def nm8_lut_host(N):
+    buf = (ctypes.c_uint8 * NM8_LUT_ENTRIES)()
+    check(load_library().bfpq_nm8_lut_host(int(N), ctypes.addressof(buf)), "bfpq_nm8_lut_host")
+    return buf                                            # (buffer protocol: _device_table copies it once)
+
+
+def nm8_lut_dev(N, device):
+    """16 MiB rank table for N:8 (built on first use per (N, device), ~0.1 s)"""
+    return _device_table("lut8", int(N), device, lambda: nm8_lut_host(N))
 
 
 # ---- tensor plumbing ------------------------------------------------------------------------
@@ -203,7 +217,7 @@ def quantize_nm(t, block_size, mant_bits, epsilon, N=0, M=0, sparsify_first=True
         elif want_exp and block_size > 0:
             exps = torch.empty((rows, (cols + block_size - 1) // block_size), dtype=torch.int8, device=dev)
         win = exp_window_dev(src.dtype, dev) if block_size > 0 else None
-        lut = nm4_lut_dev(N, dev) if M == 4 else None
+        lut = nm4_lut_dev(N, dev) if M == 4 else (nm8_lut_dev(N, dev) if (M == 8 and USE_NM8_TABLE) else None)
         fused = L.bfpq_is_fused(rows, cols, DTYPE_CODE[src.dtype], int(block_size), int(N), int(M))
         scratch = None
         if not fused and deq is None and M > 0 and block_size > 0:

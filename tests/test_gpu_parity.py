@@ -331,6 +331,14 @@ def test_nm8_in_the_flat_kernel(dname):
         assert_bits_equal(bits(deq), bits(want), dt, f"{tag} packed deq")
         back = bfp_ops.PackedBFP(codes, exps, xc.shape, dt, 3, 64, 4).dequantize()
         assert torch.equal(back.cpu().double(), want.double()), f"{tag} packed roundtrip"      # (a code has no -0)
+    # without the 16 MiB rank table the kernel replays nth_element for the ambiguous groups: same bits
+    try:
+        native.USE_NM8_TABLE = False
+        c = cfg(mant_bits=3, block_size=64, w_sparsity=True, N=4, M=8, first='q')
+        got = bfp_ops.float_to_bfp_blocked(coarse.to(DEV), **c, identifier='w')
+        assert_bits_equal(bits(got), bits(O.float_to_bfp_blocked(coarse, **c, identifier='w')), dt, "4:8 replay path")
+    finally:
+        native.USE_NM8_TABLE = True
     # the fp32 tensor still takes the general kernel (a group spans two lane items) and must agree as well
     x32 = synth(64, 512, torch.float32)
     c = cfg(mant_bits=3, block_size=64, w_sparsity=True, N=4, M=8)

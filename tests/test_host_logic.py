@@ -137,6 +137,20 @@ def test_nm_prune_mask_host_vs_oracle_random():
                 assert np.array_equal(got, want), (N, M, keys)
 
 
+def test_nm8_rank_table_matches_the_replay():
+    """the 16 MiB N:8 table (index = 3-bit 'number of smaller keys' per element) against the host nth_element replay"""
+    import random
+    rnd = random.Random(7)
+    for N in (1, 4, 6):
+        lut = np.frombuffer(native.nm8_lut_host(N), dtype=np.uint8)
+        assert int((lut != 0).sum()) == 545835                               # one entry per weak ordering of 8 elements
+        for _ in range(400):
+            keys = [rnd.choice([0, 1, 2, 3, 5, 9, 0x7f80]) for _ in range(8)]
+            less = [sum(1 for j in range(8) if keys[j] < keys[i]) for i in range(8)]
+            idx = sum(l << (3 * i) for i, l in enumerate(less))
+            assert int(lut[idx]) == native.nm_prune_mask_host(keys, N, 8), (N, keys)
+
+
 def test_is_fused_dispatch():
     L = pkg.load_library()
     assert L.bfpq_is_fused(4096, 11008, native.BF16, 64, 2, 4) == 1        # headline
