@@ -165,6 +165,16 @@ int bfpq_int_quantize(const void* in_dev, float* out_dev, int64_t outer, int64_t
 int bfpq_dequantize(const void* codes_dev, const int8_t* exp_dev, void* out_dev, int64_t rows, int64_t cols, int dtype,
                     int block_size, int mant_bits, int code_bits, void* stream);
 
+/* ---- 2:4 compaction of 4-bit codes (optional part of the packed format) --------------------
+ * codes_dev: n_bytes bytes of 4-bit codes as bfpq_quantize_nm writes them (n_bytes % 4 == 0; 8 elements per 4 bytes),
+ * every aligned group of 4 codes holding at most 2 non-zeros (N=2, M=4 in either order guarantees it).
+ * vals_dev: n_bytes / 2 bytes (per group one byte: the two kept codes, lower position in the low nibble);
+ * idx_dev: n_bytes / 4 bytes (per group 4 bits: the two positions).  0.375 B per element instead of 0.5.
+ * status_dev[0] (int32, zeroed by the caller) is set to 1 if some group had more than 2 non-zero codes.
+ * bfpq_expand24 is the exact inverse. */
+int bfpq_compact24(const void* codes_dev, void* vals_dev, void* idx_dev, int64_t n_bytes, int32_t* status_dev, void* stream);
+int bfpq_expand24(const void* vals_dev, const void* idx_dev, void* codes_dev, int64_t n_bytes, void* stream);
+
 /* ---- packed-format consumer for decode (no reference counterpart: it runs F.linear on fake-quantised tensors,
  * bfp_ops.py:187-190): out[t][n] = sum_k x[t][k] W[n][k], T <= 16 tokens, W packed HBFP
  * (4-bit codes, mant_bits <= 3) and x packed HBFP (int8 codes, mant_bits <= 7), both block 64, exact integer

@@ -263,11 +263,42 @@ class PackedBFP:
             return native.hbfp_linear_decode_tiled(x, self._tiles[0], self._tiles[1], N, self.mant_bits, x_mant_bits, epsilon)
         return native.hbfp_linear_decode(x, self.codes, self.exps, self.mant_bits, x_mant_bits, epsilon)
 
-    def save(self, path):
-        """safetensors file: tensors `codes`, `exps`; the rest as string metadata"""
+    def linear(self, x, bias=None, x_mant_bits=7, epsilon=1e-8, decode_tokens=64):
+        """F.linear(Q_in(x), W_packed, bias) for any number of tokens, W = self [N, K] (the forward of a BFPLinear whose
+        weight is held packed; activations HBFP(x_mant_bits + 1), block 64, round-half-even).
+        Up to `decode_tokens` tokens: chunks of 16 through the integer block-dot-product kernel (linear_decode), which
+        never materialises the weight.  More tokens (prefill): the weight is decoded to its dtype once per call
+        (bfpq_dequantize, a streaming pass) and multiplied by the library GEMM -- a compute-bound problem that is not
+        this engine's tier."""
+        K = self.shape[-1]
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, K)
+        T = x2.shape[0]
+        if T == 0:
+            return x.new_zeros(lead + (self.shape[0],))
+        if T <= decode_tokens and self.code_bits == 4 and self.block_size == 64 and self.shape[0] % 16 == 0 and K % 256 == 0:
+            out = torch.cat([self.linear_decode(x2[i:i + 16], x_mant_bits, epsilon) for i in range(0, T, 16)], 0) if T > 16 \
+                else self.linear_decode(x2, x_mant_bits, epsilon)
+        else:
+            xq = _quantize_nm_ref_dtype(x2, 64, x_mant_bits, epsilon, rounding_modes.DETERM)
+            out = F.linear(xq, self.dequantize().to(x.dtype))
+        if bias is not None:
+            out = out + bias
+        return out.view(lead + (self.shape[0],))
+
+    def save(self, path, compact24=False):
+        """safetensors file: tensors `codes`, `exps`; the rest as string metadata.  compact24=True stores a 2:4-sparse
+        4-bit tensor as 2 nibbles + 2 x 2-bit positions per group of 4 (`vals`, `idx`: 0.375 B/element instead of 0.5)."""
         from safetensors.torch import save_file
         meta = dict(format="hbfp-packed-v1", shape=",".join(str(d) for d in self.shape), dtype=str(self.dtype).replace("torch.", ""),
                     mant_bits=str(self.mant_bits), block_size=str(self.block_size), code_bits=str(self.code_bits))
+        if compact24:
+            assert self.code_bits == 4 and self.codes.numel() % 4 == 0
+            vals, idx = native.compact24(self.codes)
+            meta["layout"] = "compact24"
+            meta["codes_shape"] = ",".join(str(d) for d in self.codes.shape)
+            save_file({"vals": vals.cpu(), "idx": idx.cpu(), "exps": self.exps.cpu().contiguous()}, path, metadata=meta)
+            return
         save_file({"codes": self.codes.cpu().contiguous(), "exps": self.exps.cpu().contiguous()}, path, metadata=meta)
 
     @classmethod
@@ -276,7 +307,12 @@ class PackedBFP:
         with safe_open(path, framework="pt", device="cpu") as f:
             meta = f.metadata()
             assert meta.get("format") == "hbfp-packed-v1", meta
-            codes, exps = f.get_tensor("codes"), f.get_tensor("exps")
+            exps = f.get_tensor("exps")
+            if meta.get("layout") == "compact24":
+                cshape = tuple(int(d) for d in meta["codes_shape"].split(","))
+                codes = native.expand24(f.get_tensor("vals").to(device), f.get_tensor("idx").to(device)).view(cshape)
+            else:
+                codes = f.get_tensor("codes")
         shape = tuple(int(d) for d in meta["shape"].split(",")) if meta["shape"] else ()
         return cls(codes.to(device), exps.to(device), shape, getattr(torch, meta["dtype"]), int(meta["mant_bits"]),
                    int(meta["block_size"]), int(meta["code_bits"]))

@@ -354,6 +354,56 @@ __global__ void __launch_bounds__(kT) k_int_rows_reg(const void* in, float* out,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 2:4 compaction of 4-bit codes (optional part of the packed format): a group of 4 codes with at
+// most 2 non-zeros becomes 2 nibbles + 2 x 2-bit positions = 12 bits instead of 16.  One thread per 4 code bytes
+// (8 elements = 2 groups): 2 value bytes + 1 index byte, kept in two arrays so that both stay naturally aligned:
+//   vals [n/4 * 2] bytes: group g -> byte g = v0 | v1 << 4   (codes at positions p0 < p1)
+//   idx  [n/4]     bytes: groups 2t, 2t+1 -> p0a | p1a << 2 | p0b << 4 | p1b << 6
+// A group with more than 2 non-zero codes cannot be represented: status[0] is set to 1 (checked by the caller).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t compact_group(uint32_t g16, uint32_t* bad)
+{
+    // g16: 4 nibbles, element i at bits 4i.  Returns v0 | v1 << 4 | p0 << 8 | p1 << 10.
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) nz |= (((g16 >> (4 * i)) & 0xfu) != 0u) << i;
+    const int cnt = __builtin_popcount(nz);
+    if (cnt > 2) *bad = 1u;
+    uint32_t p0, p1;
+    if (cnt >= 2) { p0 = (uint32_t)__builtin_ctz(nz); p1 = (uint32_t)__builtin_ctz(nz & (nz - 1u)); }
+    else if (cnt == 1) { const uint32_t p = (uint32_t)__builtin_ctz(nz); const uint32_t o = p == 0u ? 1u : 0u; p0 = p < o ? p : o; p1 = p < o ? o : p; }
+    else { p0 = 0u; p1 = 1u; }
+    return ((g16 >> (4 * p0)) & 0xfu) | (((g16 >> (4 * p1)) & 0xfu) << 4) | (p0 << 8) | (p1 << 10);
+}
+
+__global__ void __launch_bounds__(kT) k_compact24(const uint32_t* __restrict__ codes, uint16_t* __restrict__ vals, uint8_t* __restrict__ idx,
+                                                  int64_t n, int32_t* status)
+{
+    uint32_t bad = 0;
+    for (int64_t t = (int64_t)blockIdx.x * kT + threadIdx.x; t < n; t += (int64_t)gridDim.x * kT) {
+        const uint32_t w = codes[t];
+        const uint32_t a = compact_group(w & 0xffffu, &bad), b = compact_group(w >> 16, &bad);
+        vals[t] = (uint16_t)((a & 0xffu) | ((b & 0xffu) << 8));
+        idx[t] = (uint8_t)((a >> 8) | ((b >> 8) << 4));
+    }
+    if (bad) atomicOr(reinterpret_cast<unsigned int*>(status), 1u);
+}
+
+__global__ void __launch_bounds__(kT) k_expand24(const uint16_t* __restrict__ vals, const uint8_t* __restrict__ idx, uint32_t* __restrict__ codes, int64_t n)
+{
+    for (int64_t t = (int64_t)blockIdx.x * kT + threadIdx.x; t < n; t += (int64_t)gridDim.x * kT) {
+        const uint32_t v = vals[t], p = idx[t];
+        uint32_t w = 0;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const uint32_t vb = (v >> (8 * g)) & 0xffu, pb = (p >> (4 * g)) & 0xfu;
+            w |= (((vb & 0xfu) << (4 * (pb & 3u))) | ((vb >> 4) << (4 * (pb >> 2)))) << (16 * g);
+        }
+        codes[t] = w;
+    }
+}
+
 template <int DT>
 int run_int(const void* in, float* out, int64_t outer, int64_t C, int64_t inner, float maxq, float zero, uint32_t* ws, hipStream_t s)
 {
@@ -488,6 +538,30 @@ int bfpq_dequantize(const void* codes, const int8_t* exps, void* out, int64_t ro
     if (dtype == BFPQ_F32) hipLaunchKernelGGL((k_dequant<BFPQ_F32>), grid, dim3(kT), 0, s, codes, exps, out, rows, cols, block_size, mant_bits, code_bits);
     else if (dtype == BFPQ_F16) hipLaunchKernelGGL((k_dequant<BFPQ_F16>), grid, dim3(kT), 0, s, codes, exps, out, rows, cols, block_size, mant_bits, code_bits);
     else hipLaunchKernelGGL((k_dequant<BFPQ_BF16>), grid, dim3(kT), 0, s, codes, exps, out, rows, cols, block_size, mant_bits, code_bits);
+    return (int)hipGetLastError();
+}
+
+int bfpq_compact24(const void* codes, void* vals, void* idx, int64_t n_bytes, int32_t* status, void* stream)
+{
+    if (n_bytes < 0 || n_bytes % 4 != 0) return BFPQ_E_ARG;
+    if (n_bytes == 0) return 0;
+    if (!codes || !vals || !idx || !status) return BFPQ_E_ARG;
+    const int64_t n = n_bytes / 4;
+    int64_t g = (n + kT - 1) / kT;
+    hipLaunchKernelGGL(k_compact24, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(kT), 0, (hipStream_t)stream,
+                       (const uint32_t*)codes, (uint16_t*)vals, (uint8_t*)idx, n, status);
+    return (int)hipGetLastError();
+}
+
+int bfpq_expand24(const void* vals, const void* idx, void* codes, int64_t n_bytes, void* stream)
+{
+    if (n_bytes < 0 || n_bytes % 4 != 0) return BFPQ_E_ARG;
+    if (n_bytes == 0) return 0;
+    if (!codes || !vals || !idx) return BFPQ_E_ARG;
+    const int64_t n = n_bytes / 4;
+    int64_t g = (n + kT - 1) / kT;
+    hipLaunchKernelGGL(k_expand24, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(kT), 0, (hipStream_t)stream,
+                       (const uint16_t*)vals, (const uint8_t*)idx, (uint32_t*)codes, n);
     return (int)hipGetLastError();
 }
 

@@ -67,6 +67,8 @@ def load_library():
         L.bfpq_exp_window_host.argtypes = [i32, vp]
         L.bfpq_nm4_lut_host.argtypes = [i32, vp]
         L.bfpq_nm8_lut_host.argtypes = [i32, vp]
+        L.bfpq_compact24.argtypes = [vp, vp, vp, i64, vp, vp]
+        L.bfpq_expand24.argtypes = [vp, vp, vp, i64, vp]
         L.bfpq_nm_prune_mask_host.argtypes = [vp, i32, i32]
         L.bfpq_nm_prune_mask_host.restype = u64
         L.bfpq_quantize_nm.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, dbl, i32, i32, i32, i32, u64, vp, vp, vp, vp]
@@ -88,7 +90,7 @@ def load_library():
         L.bfpq_hbfp_linear_decode.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
         L.bfpq_hbfp_linear_tiled_ok.argtypes = [i64, i64]
         L.bfpq_hbfp_linear_decode_tiled.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
-        for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
+        for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
                      "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan", "bfpq_tie_count",
                      "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize", "bfpq_hbfp_linear_slices",
                      "bfpq_hbfp_linear_decode", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled"):
@@ -97,7 +99,7 @@ def load_library():
         return _lib
 
 
-EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host",
+EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
                     "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan",
                     "bfpq_tie_count", "bfpq_threshold_apply", "bfpq_quantize_threshold")
@@ -384,6 +386,39 @@ def is_fused(t, block_size, N=0, M=0):
     """would quantize_nm take the single-pass kernel for this (contiguous) tensor?"""
     rows, cols = rows_cols(t)
     return bool(load_library().bfpq_is_fused(rows, cols, DTYPE_CODE[t.dtype], int(block_size), int(N), int(M))) and t.data_ptr() % 16 == 0
+
+
+def compact24(codes):
+    """2:4 compaction of a 4-bit code tensor (uint8, numel % 4 == 0): (vals uint8 [numel/2], idx uint8 [numel/4]).
+    Raises ValueError if some group of 4 codes has more than 2 non-zeros (synchronises to read the flag)."""
+    require_device_tensor_any(codes)
+    c = codes.contiguous().view(-1)
+    n = c.numel()
+    if n % 4:
+        raise ValueError("compact24 needs a multiple of 8 elements (4 code bytes)")
+    with torch.cuda.device(c.device):
+        vals = torch.empty(n // 2, dtype=torch.uint8, device=c.device)
+        idx = torch.empty(n // 4, dtype=torch.uint8, device=c.device)
+        status = torch.zeros(1, dtype=torch.int32, device=c.device)
+        check(load_library().bfpq_compact24(_ptr(c), _ptr(vals), _ptr(idx), n, _ptr(status), _stream(c)), "bfpq_compact24")
+    if int(status.item()):
+        raise ValueError("compact24: a group of 4 codes has more than 2 non-zeros (the tensor is not 2:4 sparse)")
+    return vals, idx
+
+
+def expand24(vals, idx):
+    """inverse of compact24: the 4-bit code bytes (uint8 [4 * idx.numel()])"""
+    require_device_tensor_any(vals)
+    n = idx.numel() * 4
+    with torch.cuda.device(vals.device):
+        codes = torch.empty(n, dtype=torch.uint8, device=vals.device)
+        check(load_library().bfpq_expand24(_ptr(vals.contiguous()), _ptr(idx.contiguous()), _ptr(codes), n, _stream(vals)), "bfpq_expand24")
+    return codes
+
+
+def require_device_tensor_any(t):
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+        raise NativeUnavailable("the BFP engine runs on a ROCm device only (no CPU fallback)")
 
 
 def mfma_tiles(wcodes, wexps):

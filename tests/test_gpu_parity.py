@@ -306,6 +306,22 @@ def test_packed_roundtrip(dname, m, blk, code_bits):
         assert torch.equal(codes2, codes) and torch.equal(exps2, exps)
 
 
+@pytest.mark.parametrize("T", [1, 16, 40, 200])
+def test_packed_linear_any_token_count(T):
+    """PackedBFP.linear: decode kernel in chunks of 16 up to 64 tokens, decode-once + library GEMM beyond; both against
+    the fp64 product of the fake-quantised operands"""
+    w = synth(256, 512, torch.bfloat16).to(DEV)
+    x = synth(T, 512, torch.bfloat16, 1.0, seed=4).to(DEV).view(1, T, 512)
+    b = synth(1, 256, torch.bfloat16, 1.0, seed=6).to(DEV).view(256)
+    pw = bfp_ops.PackedBFP.quantize(w, 3, 64, N=2, M=4)
+    got = pw.linear(x, b)
+    assert got.shape == (1, T, 256) and got.dtype == torch.bfloat16
+    xq = bfp_ops.float_to_bfp_blocked(x, **cfg(mant_bits=7, block_size=64), identifier='in').double().cpu()
+    want = xq @ pw.dequantize().double().cpu().t() + b.double().cpu()
+    err = (got.double().cpu() - want).abs().max() / want.abs().max()
+    assert float(err) < 1.2e-2, float(err)                              # bf16 output (+ bf16 bias add) rounding
+
+
 @pytest.mark.parametrize("dname", ["bf16", "f16"])
 def test_nm8_in_the_flat_kernel(dname):
     """N:8 on 16-bit dtypes runs inside the fused kernel (one lane item = one group): counted decision in registers,
@@ -331,6 +347,15 @@ def test_nm8_in_the_flat_kernel(dname):
         assert_bits_equal(bits(deq), bits(want), dt, f"{tag} packed deq")
         back = bfp_ops.PackedBFP(codes, exps, xc.shape, dt, 3, 64, 4).dequantize()
         assert torch.equal(back.cpu().double(), want.double()), f"{tag} packed roundtrip"      # (a code has no -0)
+    # special values: NaNs (one largest key), infinities, signed zeros, equal magnitudes of opposite sign -- sparsify only
+    sp = synth(8, 64, dt, 1.0, seed=11)
+    sp[0, 0:8] = torch.tensor([float('nan'), 1, -1, 1, float('nan'), -1, 0.0, -0.0], dtype=torch.float32).to(dt)
+    sp[1, 8:16] = torch.tensor([float('inf'), -float('inf'), 2, -2, 2, 0.5, -0.5, 0.5], dtype=torch.float32).to(dt)
+    sp[2, :] = 0
+    sp[3, 0:8] = torch.tensor([-0.0, 0.0, -0.0, 0.0, 3, -3, 3, -3], dtype=torch.float32).to(dt)
+    for N in (1, 3, 4, 6):
+        got = bfp_ops._structured_N_M_sparsity(sp.to(DEV), DEV, N, 8)
+        assert_bits_equal(bits(got), bits(O.structured_N_M_sparsity(sp, N, 8).view(sp.shape)), dt, f"special values {N}:8")
     # without the 16 MiB rank table the kernel replays nth_element for the ambiguous groups: same bits
     try:
         native.USE_NM8_TABLE = False
@@ -576,6 +601,34 @@ def test_packed_format_dequantize_and_safetensors(tmp_path):
     # NaN blocks survive the packed form
     xh = torch.zeros(4, 64, dtype=torch.float16, device=DEV)
     assert bool(torch.isnan(bfp_ops.PackedBFP.quantize(xh, 3, 64).dequantize()).all())
+
+
+def test_packed_compact24(tmp_path):
+    """§8f next #3 (optional part): 2:4 compaction of the 4-bit codes -- 2 nibbles + 2 x 2-bit positions per group of 4 --
+    is an exact round trip for both orders, survives the safetensors file, and refuses a tensor that is not 2:4 sparse"""
+    import os
+    xc = synth(256, 1024, torch.bfloat16)
+    x = xc.to(DEV)
+    for first in ('s', 'q'):
+        p = bfp_ops.PackedBFP.quantize(x, 3, 64, N=2, M=4, first=first)
+        vals, idx = native.compact24(p.codes)
+        assert vals.numel() == p.codes.numel() // 2 and idx.numel() == p.codes.numel() // 4
+        back = native.expand24(vals, idx).view(p.codes.shape)
+        assert torch.equal(back, p.codes), first
+        f, g = tmp_path / f"c24_{first}.safetensors", tmp_path / f"plain_{first}.safetensors"
+        p.save(str(f), compact24=True)
+        p.save(str(g))
+        q = bfp_ops.PackedBFP.load(str(f), DEV)
+        assert torch.equal(q.codes, p.codes) and torch.equal(q.exps, p.exps) and q.shape == p.shape
+        assert os.path.getsize(f) < 0.8 * os.path.getsize(g)                 # (0.375 + 1/64) / (0.5 + 1/64) = 0.76
+    # hand-made groups: 0, 1, 2 non-zeros at every position pair, negative codes
+    codes = torch.tensor([0x00, 0x00, 0x0f, 0x00, 0x00, 0x90, 0x71, 0x00, 0x07, 0x0a, 0x30, 0x0c, 0x00, 0xf1, 0x50, 0x00],
+                         dtype=torch.uint8, device=DEV)
+    v, i = native.compact24(codes)
+    assert torch.equal(native.expand24(v, i), codes)
+    dense = bfp_ops.PackedBFP.quantize(x, 3, 64)                              # no pruning: most groups have 3-4 non-zeros
+    with pytest.raises(ValueError):
+        native.compact24(dense.codes)
 
 
 def test_large_tensor_parity():
