@@ -160,7 +160,7 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v)
 
 // Tie ranks without block barriers and without a fixed traversal order: the tensor is cut into "wave
 // tiles" of 64 lane items (64 x 16 B, exactly what one wavefront handles per step).  k_tie_count writes
-// the number of threshold ties of every tile, k_tie_scan turns that array into an exclusive prefix (one
+// the number of threshold ties of every tile, k_tie_chunk_sum / k_tie_scan turn that array into exclusive prefixes (one
 // workgroup; the array is L2-sized), and a consumer wave reads prefix[tile] -- unconditionally, once per
 // tile, so that no load sits inside a branch of the streaming loop -- and adds a wave scan of its own
 // lanes' tie counts when the tile holds a tie at all.
@@ -192,13 +192,13 @@ struct ThrCtx {
 
 // The two unconditional loads a consumer wave makes per tile (nothing is loaded inside a branch of the
 // streaming loop): ties before the tile's chunk of 64 tiles, and this lane's entry of the chunk's counts.
-struct TileTies { uint32_t chunk_prefix, lane_count; };
+struct TileTies { uint32_t chunk_prefix, tile_prefix; };
 __device__ __forceinline__ TileTies tile_ties(int64_t item, const ThrCtx& t)
 {
-    const int64_t tile = item >> 6;
+    const int64_t tile = item >> 6;                        // wave-uniform: both loads are broadcasts
     TileTies r;
     r.chunk_prefix = t.coarse[tile >> 6];
-    r.lane_count = t.counts[(tile & ~(int64_t)63) + (threadIdx.x & 63)];
+    r.tile_prefix = t.counts[tile];
     return r;
 }
 
@@ -219,13 +219,9 @@ __device__ __forceinline__ uint32_t thr_prune_bits(const uint32_t* raw, bool val
     uint32_t prune = ltm;
     if (t.ranked) {
         if (__ballot(eqm != 0)) {                          // most wave tiles hold no element equal to tau
-            // ties in the tiles of this chunk that precede this tile: masked wave sum of the chunk's counts
-            const int within = (int)((item >> 6) & 63);
-            uint32_t before = ((int)(threadIdx.x & 63) < within) ? tt.lane_count : 0u;
-            for (int o = 32; o > 0; o >>= 1) before += (uint32_t)__shfl_xor((int)before, o, 64);
             const uint32_t cnt = __popc(eqm);
             const uint32_t incl = wave_incl_scan(cnt);
-            unsigned long long r = t.base + tt.chunk_prefix + before + (incl - cnt);
+            unsigned long long r = t.base + tt.chunk_prefix + tt.tile_prefix + (incl - cnt);
 #pragma unroll
             for (int j = 0; j < VEC; j++) {
                 if ((eqm >> j) & 1u) { if (r < t.need) prune |= 1u << j; r++; }
@@ -947,16 +943,24 @@ __global__ void __launch_bounds__(1024) k_select_hist(const void* in, int64_t nu
         for (; item < n_items; item += stride) {
             const int64_t pf = item + stride;
             const uint4 nv = reinterpret_cast<const uint4*>(in)[pf < last ? pf : last];
-            uint32_t raw[VEC];
-            if constexpr (VEC == 4) { raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w; }
-            else {
-                raw[0] = v.x & 0xffffu; raw[1] = v.x >> 16; raw[2] = v.y & 0xffffu; raw[3] = v.y >> 16;
-                raw[4] = v.z & 0xffffu; raw[5] = v.z >> 16; raw[6] = v.w & 0xffffu; raw[7] = v.w >> 16;
-            }
+            if constexpr (VEC == 8) {
+                // 16-bit dtypes: one pass over the whole 15-bit key (shift 0, no prefix to match): two keys per packed
+                // and/min, unconditional LDS atomics
+                const uint32_t absm = T::ABS | (T::ABS << 16), nanc = (T::INF + 1u) | ((T::INF + 1u) << 16);
+                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int j = 0; j < VEC; j++) {
-                const uint32_t key = mag_key<DT>(raw[j]);
-                if ((key & pmask) == pval) atomicAdd(&s_hist[(key >> shift) & dmask], 1u);
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t k2 = pk_min_i16_s(d[j] & absm, nanc);
+                    atomicAdd(&s_hist[k2 & 0xffffu], 1u);
+                    atomicAdd(&s_hist[k2 >> 16], 1u);
+                }
+            } else {
+                const uint32_t raw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t key = mag_key<DT>(raw[j]);
+                    if ((key & pmask) == pval) atomicAdd(&s_hist[(key >> shift) & dmask], 1u);
+                }
             }
             v = nv;
         }
@@ -1132,10 +1136,19 @@ __global__ void __launch_bounds__(kThreads) k_tie_chunk_sum(const bfpq_select_st
     if (!ranked) return;
     const int64_t c = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
     if (c >= n_chunks) return;
-    const int64_t tile = c * 64 + (threadIdx.x & 63);
-    uint32_t v = tile < n_tiles ? tie_ws[cpad + tile] : 0u;
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-    if ((threadIdx.x & 63) == 0) tie_ws[c] = v;
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = c * 64 + lane;
+    const uint32_t v = tile < n_tiles ? tie_ws[cpad + tile] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += up;
+    }
+    // the tile's count is replaced by the ties of the chunk's earlier tiles: a consumer wave then needs two broadcast
+    // dwords per tile (chunk prefix + this) instead of the chunk's 64 counts and a masked wave sum
+    if (tile < n_tiles) tie_ws[cpad + tile] = incl - v;
+    if (lane == 63) tie_ws[c] = incl;
 }
 
 // exclusive prefix of the per-chunk sums, in place (one workgroup, n = tiles / 64 entries);
@@ -1617,7 +1630,7 @@ int64_t bfpq_tie_workspace_elems(int64_t numel, int dtype)
     if (dtype < 0 || dtype > 2 || numel < 0) return BFPQ_E_ARG;
     const int vec = dtype_vec(dtype);
     const TieLayout l = tie_layout((numel + vec - 1) / vec);
-    return l.cpad + l.n_chunks * 64;
+    return l.cpad + l.n_chunks * 64 + 64;      // + slack: the ragged last sweep of a consumer reads up to 3 tiles past the end
 }
 
 int bfpq_tie_count(const void* in, int64_t numel, int dtype, void* state, uint32_t* tie_ws, void* stream)
