@@ -4,20 +4,23 @@ sys.path.insert(0, '.')
 from quantization_sparsity_interplay_amd import native
 lib = native.load_library()
 rows, cols, L, R, ROUNDS = 4096, 11008, 100, 8, 9
+NN, MM = 2, 4
+if len(sys.argv) >= 5:                      # usage: ab_grid.py rows cols N M
+    rows, cols, NN, MM = (int(a) for a in sys.argv[1:5])
 dev = torch.device('cuda:0')
 ins = [(torch.randn(rows, cols, generator=torch.Generator().manual_seed(r)) * 0.02).to(torch.bfloat16).to(dev) for r in range(R)]
 outs = [torch.empty_like(x) for x in ins]
-win = native.exp_window_dev(torch.bfloat16, dev); lut = native.nm4_lut_dev(2, dev)
+win = native.exp_window_dev(torch.bfloat16, dev); lut = native.nm4_lut_dev(NN, dev) if MM == 4 else None
 nwg = rows * cols // 8 // 256
-grids = sorted(set([ (nwg + s - 1) // s for s in (8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 22, 24, 28, 32)] + [1280, 2048, 1024]))
+grids = sorted(set([(nwg + s - 1) // s for s in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 14, 16, 18, 20, 24, 32)] + [1280, 2048, 1024]))
 graphs = {}
 for gmax in grids:
     assert lib.bfpq_tune(0, gmax) == 0
     def run():
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for i in range(L):
-            rc = lib.bfpq_quantize_nm(ins[i % R].data_ptr(), outs[i % R].data_ptr(), None, None, rows, cols, 2, 64, 3, 1e-8, 2, 4, 1, 0, 0,
-                                      win.data_ptr(), lut.data_ptr(), None, st)
+            rc = lib.bfpq_quantize_nm(ins[i % R].data_ptr(), outs[i % R].data_ptr(), None, None, rows, cols, 2, 64, 3, 1e-8, NN, MM, 1, 0, 0,
+                                      win.data_ptr(), lut.data_ptr() if lut is not None else None, None, st)
             assert rc == 0
     run(); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
