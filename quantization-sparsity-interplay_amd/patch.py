@@ -35,3 +35,53 @@ def patch_linear_layers(model, bfp_args, skip=("lm_head", "classifier", "score")
             setattr(parent, child_name, new)
             patched.append(full)
     return patched
+
+
+class PackedBFPLinear(torch.nn.Module):
+    """Inference-only Linear whose weight lives in packed HBFP form (4-bit codes + one int8 exponent per block of 64:
+    0.516 B per weight instead of 2) -- what a BFPLinear with w_sparsity / HBFP4 computes in its forward, with the weight
+    quantized ONCE.  Up to 64 tokens the product comes straight from the codes (integer block dot products on the int8
+    matrix cores, PackedBFP.linear_decode); more tokens decode the weight and use the library GEMM."""
+
+    def __init__(self, packed, bias=None, x_mant_bits=7, epsilon=1e-8):
+        super().__init__()
+        self.packed = packed
+        self.out_features, self.in_features = packed.shape
+        self.x_mant_bits, self.epsilon = int(x_mant_bits), float(epsilon)
+        self.bias = None if bias is None else torch.nn.Parameter(bias.detach(), requires_grad=False)
+
+    @classmethod
+    def from_linear(cls, lin, bfp_args):
+        """weight -> float_to_bfp_packed with the module's config (format 'bfp', block 64, mant_bits <= 3; N:M from
+        the w_sparsity keys, order from `first`); activations use mant_bits of the same config"""
+        a = bfp_ops.unpack_bfp_args(dict(bfp_args))
+        assert a['num_format'] == 'bfp' and a['sparsity_num_format'] == 'bfp' and a['block_size'] == 64 and 1 <= a['mant_bits'] <= 3, \
+            "PackedBFPLinear holds 4-bit codes: an HBFP config with block_size 64 and mant_bits <= 3 (HBFP4)"
+        sp = a['w_sparsity'] and a['sparsity_mode'] == 'structured'
+        pw = bfp_ops.PackedBFP.quantize(lin.weight.detach(), a['mant_bits'], 64, a['epsilon'], a['N'] if sp else 0, a['M'] if sp else 0, a['first'])
+        return cls(pw, lin.bias, a['mant_bits'], a['epsilon'])
+
+    def forward(self, x):
+        return self.packed.linear(x, self.bias, self.x_mant_bits, self.epsilon)
+
+    def extra_repr(self):
+        return f"in_features={self.in_features}, out_features={self.out_features}, packed_bytes={self.packed.nbytes()}"
+
+
+def pack_linear_layers(model, bfp_args, skip=("lm_head", "classifier", "score")):
+    """Inference deployment: replace nn.Linear / BFPLinear children by PackedBFPLinear (weights quantized once and
+    held as 4-bit codes; the original bf16/fp16 weight is dropped).  Needs an HBFP config with block_size 64 and
+    weight mantissa <= 3 bits (+ optional N:M).  Returns the patched names and the bytes saved."""
+    patched, saved = [], 0
+    for parent_name, parent in list(model.named_modules()):
+        for child_name, child in list(parent.named_children()):
+            full = f"{parent_name}.{child_name}" if parent_name else child_name
+            if any(full.endswith(s) for s in skip) or not isinstance(child, torch.nn.Linear):
+                continue
+            if child.in_features % 256 or child.out_features % 16:
+                continue                                    # shapes the decode kernel does not take stay as they are
+            new = PackedBFPLinear.from_linear(child, bfp_args)
+            saved += child.weight.numel() * child.weight.element_size() - new.packed.nbytes()
+            setattr(parent, child_name, new)
+            patched.append(full)
+    return patched, saved

@@ -10,7 +10,7 @@ import torch
 
 import quantization_sparsity_interplay_amd as pkg
 from quantization_sparsity_interplay_amd.bfp import bfp_ops
-from quantization_sparsity_interplay_amd.patch import patch_linear_layers
+from quantization_sparsity_interplay_amd.patch import patch_linear_layers, pack_linear_layers, PackedBFPLinear
 from oracle import oracle as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -65,6 +65,33 @@ def test_patched_llama_layers_match_oracle(dtype):
                            wq.view(torch.int32 if dtype == torch.float32 else torch.int16)), n
     for h in hooks:
         h.remove()
+
+
+@pytest.mark.gpu
+def test_packed_inference_model_matches_fake_quantised_model():
+    """deployment form: the same LLaMA with its Linear weights held as 4-bit codes (PackedBFPLinear) against the
+    BFPLinear (fake-quantise + F.linear) model -- decode-sized and prefill-sized inputs"""
+    import copy
+    from transformers import LlamaConfig, LlamaForCausalLM
+    torch.manual_seed(0)
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=768, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=4,
+                      vocab_size=1000, max_position_embeddings=64)
+    base = LlamaForCausalLM(cfg).to(torch.float32).eval()
+    args = pkg.BFPConfig.hbfp(4, 64, w_sparsity=True, N=2, M=4, sparsity_mode='structured', first='s').to_kwargs()
+    args['rounding_mode'] = 'determ'
+    fake, packed = copy.deepcopy(base), copy.deepcopy(base)
+    patch_linear_layers(fake, args)
+    fake.to("cuda:0"); packed.to("cuda:0")
+    names, saved = pack_linear_layers(packed, args)
+    assert len(names) == 2 * 7 and saved > 0
+    assert isinstance(packed.model.layers[1].mlp.down_proj, PackedBFPLinear)
+    assert type(packed.lm_head) is torch.nn.Linear
+    for shape in ((1, 12), (2, 48)):                                      # 12 tokens: integer block dot products; 96: decode + GEMM
+        tokens = torch.randint(0, 1000, shape, generator=torch.Generator().manual_seed(5)).to("cuda:0")
+        with torch.no_grad():
+            a, b = fake(tokens).logits, packed(tokens).logits
+        err = float((a - b).abs().max() / a.abs().max())
+        assert err < 2e-3, (shape, err)                                     # same quantised operands; accumulation order differs
 
 
 @pytest.mark.gpu
