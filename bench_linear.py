@@ -30,7 +30,8 @@ def main():
     rows = []
     cfg = bfpq.BFPConfig.hbfp(4, 64, w_sparsity=True, N=2, M=4, sparsity_mode='structured', first='s').to_kwargs()
     for name, tokens, fin, fout in (("q_proj", 2048, 4096, 4096), ("gate_proj", 2048, 4096, 11008), ("down_proj", 2048, 11008, 4096),
-                                    ("down_proj decode", 16, 11008, 4096), ("gate_proj decode", 16, 4096, 11008), ("down_proj decode 1 token", 1, 11008, 4096)):
+                                    ("down_proj decode", 16, 11008, 4096), ("gate_proj decode", 16, 4096, 11008), ("down_proj decode 1 token", 1, 11008, 4096),
+                                    ("down_proj decode 64 tokens", 64, 11008, 4096)):
         x = (torch.randn(tokens, fin, device=dev) * 1.0).to(torch.bfloat16)
         lin = bfp_ops.BFPLinear(fin, fout, False, **dict(cfg)).to(dev).to(torch.bfloat16)
         with torch.no_grad():
@@ -41,9 +42,9 @@ def main():
             wq = timeit(lambda: bfp_ops.float_to_bfp_blocked(lin.weight, **cfg, identifier='w'))
             aq = timeit(lambda: bfp_ops.float_to_bfp_blocked(x, **cfg, identifier='in'))
             packed = None
-            if tokens <= 16:
+            if tokens <= 64:
                 pw = bfp_ops.PackedBFP.quantize(lin.weight, 3, 64, N=2, M=4)
-                packed = timeit(lambda: pw.linear_decode(x))
+                packed = timeit(lambda: pw.linear(x))
         rows.append(dict(layer=name, tokens=tokens, in_features=fin, out_features=fout, f_linear_us=plain, bfplinear_us=ref,
                          bfplinear_cached_us=cached, weight_quant_us=wq, act_quant_us=aq, packed_decode_us=packed))
         print(rows[-1], flush=True)

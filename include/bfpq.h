@@ -190,6 +190,8 @@ int bfpq_hbfp_linear_decode(const void* wcodes_dev, const int8_t* wexp_dev, cons
  *   wtiles_dev [N/16][K/128][64][16] bytes: lane l = r + 16 q of the pair p holds the 16 codes k = 16q..16q+15 of row
  *               16*rt + r for block 2p (bytes 0-7) and block 2p+1 (bytes 8-15)
  *   wexpt_dev  [N/16][K/128][16][2] int8: exponents of the pair's two blocks per row
+ * Up to 64 tokens per call here (groups of 16 tokens walk the weight one after the other inside the one launch; xcodes_dev /
+ * xexp_dev then hold T rows).
  * One launch, no workspace: each workgroup owns one or two 16-row tiles, its waves split K and are summed in slice order
  * through LDS, so the result is reproducible. */
 int bfpq_hbfp_linear_tiled_ok(int64_t N, int64_t K);   /* 1 when the tiled layout applies to [N, K] */

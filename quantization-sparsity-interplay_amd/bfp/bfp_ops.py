@@ -251,8 +251,13 @@ class PackedBFP:
     def nbytes(self):
         return self.codes.numel() * self.codes.element_size() + self.exps.numel()
 
+    def _tiled_ok(self):
+        N, K = self.shape
+        return N % 16 == 0 and K % 128 == 0 and K >= 256
+
     def linear_decode(self, x, x_mant_bits=7, epsilon=1e-8):
-        """x @ W^T for <= 16 tokens straight from the packed weight (self is W [N, K], 4-bit codes, block 64):
+        """x @ W^T for <= 16 tokens (<= 64 with the MFMA-tiled layout) straight from the packed weight (self is W [N, K],
+        4-bit codes, block 64):
         the activation is quantized to HBFP(x_mant_bits + 1) block 64 and every block's dot product is an exact
         integer sum on the int8 matrix cores (native.hbfp_linear_decode)."""
         assert self.code_bits == 4 and self.block_size == 64 and len(self.shape) == 2
@@ -277,8 +282,8 @@ class PackedBFP:
         if T == 0:
             return x.new_zeros(lead + (self.shape[0],))
         if T <= decode_tokens and self.code_bits == 4 and self.block_size == 64 and self.shape[0] % 16 == 0 and K % 256 == 0:
-            out = torch.cat([self.linear_decode(x2[i:i + 16], x_mant_bits, epsilon) for i in range(0, T, 16)], 0) if T > 16 \
-                else self.linear_decode(x2, x_mant_bits, epsilon)
+            out = self.linear_decode(x2, x_mant_bits, epsilon) if (T <= 16 or self._tiled_ok()) else \
+                torch.cat([self.linear_decode(x2[i:i + 16], x_mant_bits, epsilon) for i in range(0, T, 16)], 0)
         else:
             xq = _quantize_nm_ref_dtype(x2, 64, x_mant_bits, epsilon, rounding_modes.DETERM)
             out = F.linear(xq, self.dequantize().to(x.dtype))

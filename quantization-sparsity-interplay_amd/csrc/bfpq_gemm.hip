@@ -110,7 +110,11 @@ __global__ void __launch_bounds__(RT == 1 ? 1024 : 512) k_hbfp_linear_decode_til
     const uint32_t wlane = lane * 16, elane = q * 8;                                      // lane takes rows 4q..4q+3 of the exponents
     // token columns past T repeat token T-1 (their results are dropped): identical addresses coalesce, so the x traffic
     // from L2 scales with the tokens actually present instead of always being 16 rows
-    const int rx = r < T ? r : T - 1;
+    // more than 16 tokens: blockIdx.y walks the groups of 16 (the weight is then re-read once per group, from the
+    // 256 MB Infinity Cache for any weight that fits it)
+    const int tok0 = blockIdx.y * 16;
+    const int Tg = T - tok0 < 16 ? T - tok0 : 16;                 // tokens of this group, 1..16
+    const int rx = tok0 + (r < Tg ? r : Tg - 1);
     const uint32_t xlane = (uint32_t)rx * K + q * 16, xelane = (uint32_t)rx * nb;
     const int4v zero = {0, 0, 0, 0};
     const int4v ones = {0x01010101, 0x01010101, 0x01010101, 0x01010101};
@@ -202,8 +206,8 @@ __global__ void __launch_bounds__(RT == 1 ? 1024 : 512) k_hbfp_linear_decode_til
         const int i = o >> 8, tok = (o >> 4) & 15, n = o & 15;
         float sum = 0.f;
         for (int w = 0; w < slices; w++) sum += red[(((size_t)w * RT + i) * 16 + tok) * 16 + n];
-        if (tok < T) {
-            const size_t d = (size_t)tok * N + (rt0 + i) * 16 + n;
+        if (tok < Tg) {
+            const size_t d = (size_t)(tok0 + tok) * N + (rt0 + i) * 16 + n;
             if constexpr (DT == BFPQ_F32) reinterpret_cast<float*>(out)[d] = sum;
             else reinterpret_cast<uint16_t*>(out)[d] = (uint16_t)f32_to_raw<DT>(sum);
         }
@@ -267,8 +271,9 @@ static int gemm_rt(int64_t N, int64_t T)
     // the x operand read from L2 is 2 bytes per weight byte unless tiles share it -- as many tiles per wave as still
     // leave >= 160 workgroups for the 256 CUs (measured: tools_dev/ab_gemm.py).
     if (T <= 4) return 1;
+    const int64_t G = (T + 15) / 16;                                // token groups: each is its own set of workgroups
     for (int rt = 4; rt > 1; rt >>= 1)
-        if (N % (16 * rt) == 0 && N / (16 * rt) >= 160) return rt;
+        if (N % (16 * rt) == 0 && N / (16 * rt) * G >= 160) return rt;
     return 1;
 }
 static int gemm_slices(int64_t N, int64_t K, int rt)
@@ -292,7 +297,7 @@ int bfpq_hbfp_linear_decode_tiled(const void* wtiles, const void* wexpt, const i
                                   void* out, int64_t T, int64_t N, int64_t K, int out_dtype,
                                   int w_mant_bits, int x_mant_bits, void* stream)
 {
-    if (T < 1 || T > 16 || out_dtype < 0 || out_dtype > 2) return BFPQ_E_ARG;
+    if (T < 1 || T > 64 || out_dtype < 0 || out_dtype > 2) return BFPQ_E_ARG;
     if (w_mant_bits < 1 || w_mant_bits > 3 || x_mant_bits < 1 || x_mant_bits > 7) return BFPQ_E_ARG;
     if (!bfpq_hbfp_linear_tiled_ok(N, K)) return BFPQ_E_UNSUPPORTED;
     if (!wtiles || !wexpt || !xcodes || !xexp || !out) return BFPQ_E_ARG;
@@ -300,7 +305,7 @@ int bfpq_hbfp_linear_decode_tiled(const void* wtiles, const void* wexpt, const i
     const int slices = gemm_slices(N, K, rt);
     const int64_t pairs = K / 128;
     const int pps = (int)((pairs + slices - 1) / slices);
-    const dim3 grid((unsigned)(N / 16 / rt)), wg((unsigned)(64 * slices));
+    const dim3 grid((unsigned)(N / 16 / rt), (unsigned)((T + 15) / 16)), wg((unsigned)(64 * slices));
     const size_t lds = (size_t)slices * rt * 256 * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
 #define BFPQ_LAUNCH_TILED(DT, RT)                                                                                                \

@@ -452,9 +452,9 @@ int run_int(const void* in, float* out, int64_t outer, int64_t C, int64_t inner,
             *rpc_out = (outer + chunks - 1) / chunks;
             return (unsigned)((outer + *rpc_out - 1) / *rpc_out);
         };
-        // min/max: every thread ends with 2*VEC atomics, so give it at least 32 rows; quantize: no atomics, fine chunks
+        // min/max: every thread ends with 2*VEC atomics, so give it at least 32 rows; quantize: per-thread scale set-up, 16 rows
         int64_t rpc_mm, rpc_q;
-        const unsigned gy_mm = chunking(32, 1024, &rpc_mm), gy_q = chunking(4, 2048, &rpc_q);
+        const unsigned gy_mm = chunking(32, 1024, &rpc_mm), gy_q = chunking(16, 1024, &rpc_q);   // (8 scale divisions per thread up front: >= 16 rows each)
         hipLaunchKernelGGL((k_int_cols_minmax_vec<DT>), dim3((unsigned)gx, gy_mm), dim3(kT), 0, s, in, outer, C, rpc_mm, ws);
         hipLaunchKernelGGL((k_int_cols_quant_vec<DT>), dim3((unsigned)gx, gy_q), dim3(kT), 0, s, in, out, outer, C, rpc_q, (const uint32_t*)ws, maxq, zero);
     } else if (inner == 1) {

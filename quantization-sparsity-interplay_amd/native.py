@@ -437,15 +437,15 @@ def hbfp_linear_decode_tiled(x, wtiles, wexpt, N, w_mant_bits, x_mant_bits=7, ep
     L = load_library()
     K = x.shape[-1]
     T = x.numel() // K
-    if T < 1 or T > 16 or not L.bfpq_hbfp_linear_tiled_ok(N, K):
-        raise ValueError(f"hbfp_linear_decode_tiled needs 1..16 tokens, N % 16 == 0, K % 128 == 0 and K >= 256 (got T={T}, N={N}, K={K})")
+    if T < 1 or T > 64 or not L.bfpq_hbfp_linear_tiled_ok(N, K):
+        raise ValueError(f"hbfp_linear_decode_tiled needs 1..64 tokens, N % 16 == 0, K % 128 == 0 and K >= 256 (got T={T}, N={N}, K={K})")
     dev = x.device
     out_dtype = out_dtype or x.dtype
     with torch.cuda.device(dev):
-        xc16 = torch.empty((16, K), dtype=torch.int8, device=dev)
-        xe16 = torch.empty((16, K // 64), dtype=torch.int8, device=dev)
+        xc16 = torch.empty((T, K), dtype=torch.int8, device=dev)          # (token columns past T re-read row T-1: no padding rows)
+        xe16 = torch.empty((T, K // 64), dtype=torch.int8, device=dev)
         quantize_nm(x.reshape(T, K), 64, x_mant_bits, epsilon, want_deq=False, code_bits=8, want_exp=True,
-                    codes_out=xc16[:T], exps_out=xe16[:T])
+                    codes_out=xc16, exps_out=xe16)
         out = torch.empty((T, N), dtype=out_dtype, device=dev)
         check(L.bfpq_hbfp_linear_decode_tiled(_ptr(wtiles), _ptr(wexpt), _ptr(xc16), _ptr(xe16), _ptr(out), T, N, K,
                                               DTYPE_CODE[out_dtype], int(w_mant_bits), int(x_mant_bits), _stream(x)),
