@@ -687,6 +687,12 @@ def test_packed_consumer_decode_linear(N, K, T, dname):
         got32 = native.hbfp_linear_decode(x, pw.codes, pw.exps, 3, 7, out_dtype=torch.float32)
         err32 = (got32.double().cpu() - want).abs().max() / want.abs().max()
         assert float(err32) < 2e-6, float(err32)
+    if K % 128 == 0 and K >= 256:                                   # HBFP4 activations (the W4A4 pairing of an HBFP4 config)
+        g4 = pw.linear_decode(x, x_mant_bits=3)
+        xq4 = bfp_ops.float_to_bfp_blocked(x, **cfg(mant_bits=3, block_size=64), identifier='in').double().cpu()
+        want4 = xq4 @ wq.t()
+        e4 = (g4.double().cpu() - want4).abs().max() / want4.abs().max()
+        assert float(e4) < tol, ("W4A4", float(e4), tol)
     if K % 128 == 0:                                                # the MFMA-tiled weight layout: same sums, other slice order
         tiles, expt = native.mfma_tiles(pw.codes, pw.exps)
         got32t = native.hbfp_linear_decode_tiled(x, tiles, expt, N, 3, 7, out_dtype=torch.float32)
