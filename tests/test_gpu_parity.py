@@ -705,3 +705,34 @@ def test_packed_consumer_decode_linear(N, K, T, dname):
                 assert torch.equal(g, got32t) or float((g.double().cpu() - want).abs().max() / want.abs().max()) < 2e-6, rt
         finally:
             native.load_library().bfpq_tune(1, 0)
+
+
+def test_dist_paths_with_the_native_engine_on_rccl():
+    """dist.py end to end on the device with the HIP engine and RCCL (backend "nccl"), one rank: the gloo tests cover the
+    multi-rank protocol with a stand-in engine, this covers the real kernels, streams and collectives behind the same
+    functions -- sharded quantize (+ gather), the unstructured exchange (histogram all-reduce, tie all-gather), the
+    side-stream overlapped gather and the packed-bytes gather."""
+    import torch.distributed as dist
+    from quantization_sparsity_interplay_amd import dist as D
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        xc = synth(256, 1024, torch.bfloat16)
+        x = xc.to(DEV)
+        c = cfg(w_sparsity=True)
+        single = bfp_ops.float_to_bfp_blocked(x, **c, identifier='w')
+        assert torch.equal(D.float_to_bfp_blocked_sharded(x, 256, gather=True, identifier='w', **c), single)
+        for first in ('s', 'q'):
+            cu = cfg(w_sparsity=True, sparsity_mode='unstructured', sparsity_frac=0.5, first=first)
+            a = D.float_to_bfp_blocked_sharded(x, 256, gather=True, identifier='w', **cu)
+            assert_bits_equal(bits(a), bits(bfp_ops.float_to_bfp_blocked(x, **cu, identifier='w')), torch.bfloat16, f"sharded unstructured {first}")
+        g = D.gather_overlapped(x, 256, lambda p: bfp_ops.float_to_bfp_blocked(p, **c, identifier='w'), chunks=4)
+        assert torch.equal(g, single)
+        pk = D.all_gather_packed(x, 256, 3, 64, N=2, M=4)
+        assert torch.equal(pk.float(), single.float())
+        codes, exps = D.float_to_bfp_packed_sharded(x, 256, 3, 64, gather=True, N=2, M=4)
+        c1, e1 = bfp_ops.float_to_bfp_packed(x, 3, 64, N=2, M=4)
+        assert torch.equal(codes, c1) and torch.equal(exps, e1)
+    finally:
+        dist.destroy_process_group()
