@@ -275,22 +275,11 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
 {
     using T = Traits<DT>;
     constexpr int VEC = T::VEC;
-    __shared__ uint8_t s_win[512];
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[512];
     __shared__ uint2 s_mask[NM == 4 && VEC == 8 ? 736 : 1];      // 16-bit dtypes: AND masks for the two dwords of a group
     __shared__ uint8_t s_keep[NM == 4 && VEC == 4 ? 736 : 1];    // fp32: 4-bit keep mask
     __shared__ uint64_t s_kv[NM == 8 ? 8 * kThreads : 1];        // N:8: column per thread for the nth_element replay (rare)
-    for (int i = threadIdx.x; i < 512; i += kThreads)
-        s_win[i] = (a.exp_win && i < BFPQ_EXP_WIN_ENTRIES) ? a.exp_win[i] : 0;
-    if constexpr (NM == 4) {
-        for (int i = threadIdx.x; i < BFPQ_NM4_LUT_ENTRIES; i += kThreads) {
-            const uint32_t k = a.nm_lut[i];
-            if constexpr (VEC == 8)
-                s_mask[i] = make_uint2(((k & 1u) ? 0xffffu : 0u) | ((k & 2u) ? 0xffff0000u : 0u),
-                                       ((k & 4u) ? 0xffffu : 0u) | ((k & 8u) ? 0xffff0000u : 0u));
-            else s_keep[i] = (uint8_t)k;
-        }
-    }
-    __syncthreads();
+    // (the tables are filled further down, behind the first tile's load: one memory round trip for everything)
 
     const bool do_quant = a.lpb > 0;
     const int64_t stride = (int64_t)gridDim.x * kThreads;
@@ -579,6 +568,39 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
     const int64_t full = a.n_items / stride;                               // sweeps in which every thread has an item
     int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     u4v c0 = fetch(item);
+    // Tables -> LDS, issued BEHIND the first tile's load and as one dword per thread.  The byte-per-thread loops this
+    // replaces were 5 dependent global round trips (3 for the 729-byte N:M table, 2 for the window table) in front of the
+    // first load: invisible on a 90 MB tensor (the CU's other workgroups cover it), a large part of the run time of the
+    // launch-latency-sized tensors (OPT-125m, ViT).
+    {
+        const int t = threadIdx.x;
+        auto put = [&](int i, uint32_t k) __attribute__((always_inline)) {
+            if constexpr (NM == 4 && VEC == 8)
+                s_mask[i] = make_uint2(((k & 1u) ? 0xffffu : 0u) | ((k & 2u) ? 0xffff0000u : 0u),
+                                       ((k & 4u) ? 0xffffu : 0u) | ((k & 8u) ? 0xffff0000u : 0u));
+            else if constexpr (NM == 4) s_keep[i] = (uint8_t)k;
+        };
+        const bool win_al = a.exp_win && (reinterpret_cast<uintptr_t>(a.exp_win) & 3u) == 0;
+        const bool lut_al = NM == 4 && (reinterpret_cast<uintptr_t>(a.nm_lut) & 3u) == 0;
+        uint32_t w = 0, k4 = 0;
+        if (win_al && t < BFPQ_EXP_WIN_ENTRIES / 4) w = reinterpret_cast<const uint32_t*>(a.exp_win)[t];
+        if constexpr (NM == 4) {
+            if (lut_al && t < BFPQ_NM4_LUT_ENTRIES / 4) k4 = reinterpret_cast<const uint32_t*>(a.nm_lut)[t];
+            else if (lut_al && t == BFPQ_NM4_LUT_ENTRIES / 4) k4 = a.nm_lut[BFPQ_NM4_LUT_ENTRIES - 1];    // 729 = 4 * 182 + 1
+        }
+        if (win_al) { if (t < 128) reinterpret_cast<uint32_t*>(s_win)[t] = w; }
+        else
+            for (int i = t; i < 512; i += kThreads) s_win[i] = (a.exp_win && i < BFPQ_EXP_WIN_ENTRIES) ? a.exp_win[i] : 0;
+        if constexpr (NM == 4) {
+            if (lut_al) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (4 * t + j < BFPQ_NM4_LUT_ENTRIES) put(4 * t + j, (k4 >> (8 * j)) & 0xffu);
+            } else
+                for (int i = t; i < BFPQ_NM4_LUT_ENTRIES; i += kThreads) put(i, a.nm_lut[i]);
+        }
+    }
+    __syncthreads();
     // One more memory op behind the first load, result unused.  At the loop top the back edge arrives with [load, store]
     // outstanding and the entry edge with [load] only; one s_waitcnt immediate must serve both edges, so the compiler
     // emitted vmcnt(0) and every wave waited for its just-issued store once per iteration.  With [load, dummy] on the
