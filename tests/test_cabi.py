@@ -31,6 +31,17 @@ def test_argument_validation_without_gpu():
     assert L.bfpq_int_quantize(one, one, 1, 4, 4, 5, 8, n, n) == -1
     assert L.bfpq_tune(0, 0) == -1 and L.bfpq_tune(99, 5) == -1 and L.bfpq_tune(0, 1280) == 0
     assert L.bfpq_is_fused(4, 64, 5, 64, 2, 4) == 0
+    # packed-format entry points
+    assert L.bfpq_compact24(one, one, one, 6, one, n) == -1                                     # code bytes not a multiple of 4
+    assert L.bfpq_compact24(one, one, one, 8, n, n) == -1                                       # no status word
+    assert L.bfpq_compact24(one, one, one, 0, one, n) == 0 and L.bfpq_expand24(one, one, one, 0, n) == 0
+    assert L.bfpq_hbfp_linear_tiled_ok(4096, 11008) == 1 and L.bfpq_hbfp_linear_tiled_ok(4096, 128) == 0 and L.bfpq_hbfp_linear_tiled_ok(100, 1024) == 0
+    assert L.bfpq_hbfp_linear_decode_tiled(one, one, one, one, one, 65, 4096, 11008, native.BF16, 3, 7, n) == -1     # more than 64 tokens
+    assert L.bfpq_hbfp_linear_decode_tiled(one, one, one, one, one, 1, 4096, 11008, native.BF16, 4, 7, n) == -1      # weight mantissa > 3 bits
+    assert L.bfpq_hbfp_linear_decode_tiled(one, one, one, one, one, 1, 4096, 1000, native.BF16, 3, 7, n) == -2       # shape the tiled layout does not take
+    assert L.bfpq_hbfp_linear_decode(one, one, one, one, one, one, 17, 4096, 11008, native.BF16, 3, 7, n) == -1      # row-major layout: <= 16 tokens
+    assert L.bfpq_nm8_lut_host(0, one) == -1 and L.bfpq_nm8_lut_host(4, n) == -1
+    assert L.bfpq_tune(1, 3) == -1 and L.bfpq_tune(1, 2) == 0 and L.bfpq_tune(1, 0) == 0
 
 
 @pytest.mark.gpu
