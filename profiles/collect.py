@@ -6,12 +6,13 @@ import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 prof = os.path.join(ROOT, "gpurun_out", "prof")
-stats = glob.glob(os.path.join(prof, "trace", "*", "*_kernel_stats.csv"))[0]
+newest = lambda pattern: max(glob.glob(pattern), key=os.path.getmtime)      # gpurun merges runs into the same directory: take the latest
+stats = newest(os.path.join(prof, "trace", "*", "*_kernel_stats.csv"))
 shutil.copy(stats, os.path.join(ROOT, "profiles", f"{tag}_kernel_stats_headline.csv"))
 top = next(r for r in csv.DictReader(open(stats)) if "k_fused_flat" in r["Name"])
 vals = {}
 for kind in ("fetch", "write"):
-    f = glob.glob(os.path.join(prof, f"pmc_{kind}", "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(prof, f"pmc_{kind}", "*", "*_counter_collection.csv"))
     rows = [r for r in csv.DictReader(open(f)) if "k_fused_flat" in r["Kernel_Name"]]
     v = [float(r["Counter_Value"]) for r in rows]
     vals[kind] = (sum(v) / len(v), len(v), rows[0])
