@@ -147,6 +147,20 @@ int bfpq_quantize_threshold(const void* in_dev, void* out_deq_dev, void* out_cod
                             const void* state_dev, const uint32_t* tie_ws_dev, const int64_t* tie_base_dev,
                             void* scratch_dev, void* stream);
 
+/* The same result in ONE pass over the tensor and without bfpq_tie_count (single device, fused shapes only, else
+ * BFPQ_E_UNSUPPORTED): workgroups hold units of 2048 lane items in registers, count their threshold ties and learn the
+ * ties of all earlier units by decoupled look-back on packed (flag, count) words in tie_ws_dev (bfpq_tie_workspace_elems
+ * entries, 16-byte aligned).  Same flat-index-first tie rule, bit-identical output.
+ * state_dev->reserved[1] is set to 1 if a look-back spin hit its cap (never in a healthy run). */
+int bfpq_quantize_threshold_onepass(const void* in_dev, void* out_deq_dev, void* out_codes_dev, int8_t* out_exp_dev,
+                                    int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits, double epsilon,
+                                    int code_bits, uint64_t stoch_seed, const uint8_t* exp_win_dev,
+                                    void* state_dev, uint32_t* tie_ws_dev, int status_prepared, void* stream);
+/* bfpq_select_hist that also zeroes, for free, the unit status words the one-pass apply of the same tensor needs (pass
+ * status_prepared = 1 to bfpq_quantize_threshold_onepass then; with 0 it zeroes them itself with a memset) */
+int bfpq_select_hist_prepare(const void* in_dev, int64_t numel, int dtype, int pass, const void* state_dev, uint32_t* hist_dev,
+                             uint32_t* tie_ws_dev, void* stream);
+
 /* ---- 'int' per-channel format (replaces _quantize's 'int' branch, bfp_ops.py:111-120, i.e.
  * int_ops.Quantizer.configure/find_params/quantize with the defaults perchannel=True, sym=True) -------
  * The tensor is viewed as [outer, C, inner] with the channel in the middle (int_ops.py:38-50):

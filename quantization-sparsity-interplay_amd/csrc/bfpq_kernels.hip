@@ -138,6 +138,8 @@ struct FusedArgs {
     const bfpq_select_state* sel;   // NM == -1 (global magnitude threshold): select result,
     const uint32_t* tie_counts;     //   ties per wave-chunk (k_tie_count),
     const int64_t* tie_base;        //   ties held by lower ranks (nullable)
+    unsigned long long* unit_status;  // NM == -1, one-pass mode: flag + tie count per unit of kThreads x 8 items (zeroed); else null
+    int* unit_error;                  //   set to 1 if a look-back spin ran into its cap (never in a healthy run)
 };
 
 // wave-level inclusive scan (lane order)
@@ -288,6 +290,7 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
 
     // N:M mask on the 4 dwords of an item (16-bit dtypes: 2 groups of 4; fp32: 1 group)
     ThrCtx thr;
+    bool unit_mode = false;
     bool item_valid = true;
     int64_t item_index = 0;
     if constexpr (NM == -1) thr.load(a.sel, a.tie_counts, a.tie_base, a.n_items);
@@ -299,7 +302,8 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
                 raw[0] = d0 & 0xffffu; raw[1] = d0 >> 16; raw[2] = d1 & 0xffffu; raw[3] = d1 >> 16;
                 raw[4] = d2 & 0xffffu; raw[5] = d2 >> 16; raw[6] = d3 & 0xffffu; raw[7] = d3 >> 16;
             }
-            const uint32_t prune = thr_prune_bits<DT>(raw, item_valid, item_index, tile_ties(item_index, thr), thr);
+            const TileTies tt = unit_mode ? TileTies{0u, 0u} : tile_ties(item_index, thr);   // unit mode: thr.base carries the rank
+            const uint32_t prune = thr_prune_bits<DT>(raw, item_valid, item_index, tt, thr);
             if constexpr (VEC == 4) {
                 d0 = (prune & 1u) ? 0u : d0; d1 = (prune & 2u) ? 0u : d1; d2 = (prune & 4u) ? 0u : d2; d3 = (prune & 8u) ? 0u : d3;
             } else {
@@ -601,6 +605,100 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
         }
     }
     __syncthreads();
+    if constexpr (NM == -1) {
+        if (a.unit_status != nullptr && thr.ranked) {
+            // ONE-PASS unstructured apply.  A workgroup takes units of kThreads x IPT consecutive lane items (32 KiB of
+            // bf16), keeps a unit in registers, counts its threshold ties per wave tile, publishes the unit's count in a
+            // packed (flag, value) word and obtains the number of ties in all earlier units by decoupled look-back over
+            // the lower-numbered units (device-scope atomics on those words only -- no __threadfence(), which is an L2
+            // write-back on this part); then prunes with exact flat-order ranks, quantizes and stores from the registers.
+            // The tensor is read once instead of twice (no k_tie_count pass) and three launches disappear.
+            // Progress: the launcher bounds the grid by the resident capacity, so every unit waited for belongs to a
+            // workgroup that is running; spins are capped all the same (a.unit_error).
+            constexpr int IPT = 8, NW = kThreads / 64;
+            constexpr unsigned long long F_AGG = 1ull << 62, F_PRE = 2ull << 62, VMASK = (1ull << 62) - 1;
+            __shared__ uint32_t s_cnt[IPT * NW];                                // ties per wave tile, order (i, wave)
+            __shared__ uint4 s_items[IPT][kThreads];                            // the unit, parked per thread between count and apply
+                                                                                // (in registers the 8 inlined bodies cost 160 VGPRs)
+            __shared__ unsigned long long s_unit_base;
+            unit_mode = true;
+            const unsigned long long base0 = thr.base;
+            const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            const int64_t unit_items = (int64_t)kThreads * IPT;
+            const int64_t n_units = (a.n_items + unit_items - 1) / unit_items;
+            u4v d[IPT];
+            {
+                const int64_t f0 = (int64_t)blockIdx.x * unit_items + threadIdx.x;
+#pragma unroll
+                for (int i = 0; i < IPT; i++) d[i] = fetch(f0 + (int64_t)i * kThreads);
+            }
+            for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+                const int64_t first = u * unit_items + threadIdx.x;
+#pragma unroll
+                for (int i = 0; i < IPT; i++) {
+                    const uint32_t dw[4] = {d[i].x, d[i].y, d[i].z, d[i].w};
+                    uint32_t cnt = 0;
+#pragma unroll
+                    for (int j = 0; j < VEC; j++) {
+                        const uint32_t r = VEC == 4 ? dw[j] : ((dw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+                        cnt += mag_key<DT>(r) == thr.tau;
+                    }
+                    if (first + (int64_t)i * kThreads >= a.n_items) cnt = 0;
+                    for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, 64);
+                    if (lane == 0) s_cnt[i * NW + w] = cnt;
+                    s_items[i][threadIdx.x] = u4(d[i]);
+                }
+                __syncthreads();
+                {                                                   // the next unit's loads fly during the look-back and the apply
+                    const int64_t fn = (u + gridDim.x) * unit_items + threadIdx.x;      // (clamped by fetch past the end)
+#pragma unroll
+                    for (int i = 0; i < IPT; i++) d[i] = fetch(fn + (int64_t)i * kThreads);
+                }
+                if (w == 0) {
+                    const uint32_t v = lane < IPT * NW ? s_cnt[lane] : 0u;
+                    const uint32_t incl = wave_incl_scan(v);
+                    const unsigned long long total = (unsigned long long)(uint32_t)__shfl((int)incl, IPT * NW - 1, 64);
+                    if (lane == 0)
+                        __hip_atomic_store(&a.unit_status[u], (u == 0 ? F_PRE : F_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned long long excl = 0;
+                    if (u > 0) {
+                        int64_t look = u - 1;
+                        int spins = 0;
+                        for (;;) {
+                            const int64_t idx = look - lane;
+                            const unsigned long long st = idx >= 0 ? __hip_atomic_load(&a.unit_status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                                   : F_PRE;             // in front of unit 0: prefix 0
+                            const uint32_t flag = (uint32_t)(st >> 62);
+                            const unsigned long long m_pre = __ballot(flag == 2u), m_empty = __ballot(flag == 0u);
+                            const int fp = m_pre ? __ffsll((long long)m_pre) - 1 : 64;  // nearest predecessor with a prefix
+                            const unsigned long long nearer = fp >= 64 ? ~0ull : ((1ull << fp) - 1ull);
+                            if (m_empty & nearer) {                                    // a nearer unit has not published yet
+                                if (++spins > (1 << 22)) { if (lane == 0 && a.unit_error) *a.unit_error = 1; break; }
+                                __builtin_amdgcn_s_sleep(1);
+                                continue;
+                            }
+                            excl += wave_sum64(lane <= fp ? (st & VMASK) : 0ull);
+                            if (fp < 64) break;
+                            look -= 64;
+                        }
+                        if (lane == 0)
+                            __hip_atomic_store(&a.unit_status[u], F_PRE | ((excl + total) & VMASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (lane < IPT * NW) s_cnt[lane] = incl - v;                        // ties of the unit's earlier wave tiles
+                    if (lane == 0) s_unit_base = excl;
+                }
+                __syncthreads();
+                const unsigned long long ubase = base0 + s_unit_base;
+#pragma unroll 1
+                for (int i = 0; i < IPT; i++) {
+                    thr.base = ubase + s_cnt[i * NW + w];
+                    body(std::true_type{}, first + (int64_t)i * kThreads, s_items[i][threadIdx.x]);
+                }
+                __syncthreads();                                                        // s_cnt is rewritten by the next unit
+            }
+            return;
+        }
+    }
     // One more memory op behind the first load, result unused.  At the loop top the back edge arrives with [load, store]
     // outstanding and the entry edge with [load] only; one s_waitcnt immediate must serve both edges, so the compiler
     // emitted vmcnt(0) and every wave waited for its just-issued store once per iteration.  With [load, dummy] on the
@@ -942,8 +1040,11 @@ __host__ __device__ inline void select_digit(int dtype, int pass, int* shift, in
 
 template <int DT>
 __global__ void __launch_bounds__(1024) k_select_hist(const void* in, int64_t numel, int shift, int nbits, int first,
-                                                      const bfpq_select_state* st, uint32_t* hist)
+                                                      const bfpq_select_state* st, uint32_t* hist,
+                                                      unsigned long long* zero_ptr, int64_t zero_n)
 {
+    // (the one-pass apply that follows needs its unit status words zeroed: done here, for free, instead of a memset node)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += (int64_t)gridDim.x * blockDim.x) zero_ptr[i] = 0ull;
     using T = Traits<DT>;
     using raw_t = typename T::raw_t;
     constexpr int VEC = T::VEC;
@@ -1312,11 +1413,39 @@ int launch_fused_l(const FusedArgs& a, hipStream_t s)
     return launch_fused_o<DT, NM, SFIRST, STOCH, false>(a, s);
 }
 
+// resident capacity of the device for a kernel (workgroups), cached per kernel: the one-pass unstructured mode spins
+// on lower-numbered units, so its grid must not exceed what can run at once
+template <typename K>
+int resident_workgroups(K kernel)
+{
+    static int cus = 0;                                           // per process: one device model per node
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 64;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    return per_cu * cus;
+}
+
 template <int DT>
 int launch_fused_threshold(const FusedArgs& a, hipStream_t s)
 {
-    const dim3 grid(grid_for(a.n_items)), block(kThreads);
+    dim3 grid(grid_for(a.n_items)), block(kThreads);
     const bool deq_only = a.out_deq && !a.out_codes && !a.out_exp;
+    if (a.unit_status) {                                         // one-pass mode: units of 2048 items, co-resident workgroups only
+        const int64_t n_units = (a.n_items + 2047) / 2048;
+        int cap;
+        if (a.seed) cap = resident_workgroups(k_fused_flat<DT, -1, true, true, -1, false>);
+        else if (deq_only && a.lpb == 8) cap = resident_workgroups(k_fused_flat<DT, -1, true, false, 8, true>);
+        else if (deq_only && a.lpb == 4) cap = resident_workgroups(k_fused_flat<DT, -1, true, false, 4, true>);
+        else if (deq_only) cap = resident_workgroups(k_fused_flat<DT, -1, true, false, -1, true>);
+        else cap = resident_workgroups(k_fused_flat<DT, -1, true, false, -1, false>);
+        int64_t g = n_units < cap ? n_units : cap;                     // (equal units per workgroup, i.e. fewer workgroups, measured slower)
+        if (g > kMaxGrid) g = kMaxGrid;
+        grid = dim3((unsigned)(g < 1 ? 1 : g));
+    }
     if (a.seed) {
         hipLaunchKernelGGL((k_fused_flat<DT, -1, true, true, -1, false>), grid, block, 0, s, a);
     } else if (deq_only) {
@@ -1545,7 +1674,7 @@ int bfpq_quantize_nm(const void* in, void* out_deq, void* out_codes, int8_t* out
         a.lpb = block_size ? block_size / dtype_vec(dtype) : 0;
         a.mant_bits = mant_bits; a.N = N; a.code_bits = code_bits;
         a.force_slow = mant_bits > (dtype == BFPQ_F32 ? 24 : (dtype == BFPQ_F16 ? 11 : 8));
-        a.sel = nullptr; a.tie_counts = nullptr; a.tie_base = nullptr;
+        a.sel = nullptr; a.tie_counts = nullptr; a.tie_base = nullptr; a.unit_status = nullptr; a.unit_error = nullptr;
         if (dtype == BFPQ_F32) return launch_fused<BFPQ_F32>(a, M, sparsify_first != 0, s);
         if (dtype == BFPQ_F16) return launch_fused<BFPQ_F16>(a, M, sparsify_first != 0, s);
         return launch_fused<BFPQ_BF16>(a, M, sparsify_first != 0, s);
@@ -1565,7 +1694,7 @@ int bfpq_quantize_nm(const void* in, void* out_deq, void* out_codes, int8_t* out
             a.lpb = block_size / dtype_vec(dtype);
             a.mant_bits = mant_bits; a.N = 0; a.code_bits = code_bits;
             a.force_slow = mant_bits > (dtype == BFPQ_F32 ? 24 : (dtype == BFPQ_F16 ? 11 : 8));
-            a.sel = nullptr; a.tie_counts = nullptr; a.tie_base = nullptr;
+            a.sel = nullptr; a.tie_counts = nullptr; a.tie_base = nullptr; a.unit_status = nullptr; a.unit_error = nullptr;
             if (dtype == BFPQ_F32) return launch_fused<BFPQ_F32>(a, 0, true, s);
             if (dtype == BFPQ_F16) return launch_fused<BFPQ_F16>(a, 0, true, s);
             return launch_fused<BFPQ_BF16>(a, 0, true, s);
@@ -1601,7 +1730,24 @@ int bfpq_nm_sparsify(const void* in, void* out, int64_t rows, int64_t cols, int 
 
 int bfpq_select_passes(int dtype) { return dtype == BFPQ_F32 ? 3 : 1; }
 
+static int select_hist_impl(const void* in, int64_t numel, int dtype, int pass, const void* state, uint32_t* hist, void* stream,
+                            unsigned long long* zero_ptr, int64_t zero_n);
+
 int bfpq_select_hist(const void* in, int64_t numel, int dtype, int pass, const void* state, uint32_t* hist, void* stream)
+{
+    return select_hist_impl(in, numel, dtype, pass, state, hist, stream, nullptr, 0);
+}
+
+int bfpq_select_hist_prepare(const void* in, int64_t numel, int dtype, int pass, const void* state, uint32_t* hist,
+                             uint32_t* tie_ws, void* stream)
+{
+    if (!tie_ws || dtype < 0 || dtype > 2 || numel < 0) return BFPQ_E_ARG;
+    const int64_t n_items = numel / dtype_vec(dtype);
+    return select_hist_impl(in, numel, dtype, pass, state, hist, stream, reinterpret_cast<unsigned long long*>(tie_ws), (n_items + 2047) / 2048);
+}
+
+static int select_hist_impl(const void* in, int64_t numel, int dtype, int pass, const void* state, uint32_t* hist, void* stream,
+                            unsigned long long* zero_ptr, int64_t zero_n)
 {
     if (!in || !state || !hist || dtype < 0 || dtype > 2 || numel < 0 || pass < 0 || pass >= bfpq_select_passes(dtype)) return BFPQ_E_ARG;
     int shift, nbits;
@@ -1614,15 +1760,15 @@ int bfpq_select_hist(const void* in, int64_t numel, int dtype, int pass, const v
     const bfpq_select_state* st = (const bfpq_select_state*)state;
     hipError_t err = hipSuccess;
     if (dtype == BFPQ_F32) {
-        hipLaunchKernelGGL((k_select_hist<BFPQ_F32>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, pass == 0, st, hist);
+        hipLaunchKernelGGL((k_select_hist<BFPQ_F32>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, pass == 0, st, hist, zero_ptr, zero_n);
     } else if (dtype == BFPQ_F16) {
         err = hipFuncSetAttribute((const void*)k_select_hist<BFPQ_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return (int)err;
-        hipLaunchKernelGGL((k_select_hist<BFPQ_F16>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, pass == 0, st, hist);
+        hipLaunchKernelGGL((k_select_hist<BFPQ_F16>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, pass == 0, st, hist, zero_ptr, zero_n);
     } else {
         err = hipFuncSetAttribute((const void*)k_select_hist<BFPQ_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (err != hipSuccess) return (int)err;
-        hipLaunchKernelGGL((k_select_hist<BFPQ_BF16>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, pass == 0, st, hist);
+        hipLaunchKernelGGL((k_select_hist<BFPQ_BF16>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, pass == 0, st, hist, zero_ptr, zero_n);
     }
     return (int)hipGetLastError();
 }
@@ -1693,11 +1839,41 @@ int bfpq_threshold_apply(const void* in, void* out, int64_t numel, int dtype, co
     return (int)hipGetLastError();
 }
 
+static int quantize_threshold_impl(const void* in, void* out_deq, void* out_codes, int8_t* out_exp,
+                                   int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits, double epsilon,
+                                   int code_bits, uint64_t stoch_seed, const uint8_t* exp_win,
+                                   const void* state, const uint32_t* counts, const int64_t* tie_base,
+                                   void* scratch, void* stream, bool onepass, bool status_prepared = false);
+
 int bfpq_quantize_threshold(const void* in, void* out_deq, void* out_codes, int8_t* out_exp,
                             int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits, double epsilon,
                             int code_bits, uint64_t stoch_seed, const uint8_t* exp_win,
                             const void* state, const uint32_t* counts, const int64_t* tie_base,
                             void* scratch, void* stream)
+{
+    return quantize_threshold_impl(in, out_deq, out_codes, out_exp, rows, cols, dtype, block_size, mant_bits, epsilon, code_bits,
+                                   stoch_seed, exp_win, state, counts, tie_base, scratch, stream, false);
+}
+
+int bfpq_quantize_threshold_onepass(const void* in, void* out_deq, void* out_codes, int8_t* out_exp,
+                                    int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits, double epsilon,
+                                    int code_bits, uint64_t stoch_seed, const uint8_t* exp_win,
+                                    void* state, uint32_t* tie_ws, int status_prepared, void* stream)
+{
+    if (dtype < 0 || dtype > 2 || rows < 0 || cols < 0 || block_size <= 0) return BFPQ_E_ARG;
+    if (rows * cols && !fused_shape_ok(rows, cols, dtype, block_size, 0, 0)) return BFPQ_E_UNSUPPORTED;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out_deq) | reinterpret_cast<uintptr_t>(out_codes) |
+                           reinterpret_cast<uintptr_t>(tie_ws)) & 15u) == 0;
+    if (!aligned) return BFPQ_E_UNSUPPORTED;
+    return quantize_threshold_impl(in, out_deq, out_codes, out_exp, rows, cols, dtype, block_size, mant_bits, epsilon, code_bits,
+                                   stoch_seed, exp_win, state, tie_ws, nullptr, nullptr, stream, true, status_prepared != 0);
+}
+
+static int quantize_threshold_impl(const void* in, void* out_deq, void* out_codes, int8_t* out_exp,
+                                   int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits, double epsilon,
+                                   int code_bits, uint64_t stoch_seed, const uint8_t* exp_win,
+                                   const void* state, const uint32_t* counts, const int64_t* tie_base,
+                                   void* scratch, void* stream, bool onepass, bool status_prepared)
 {
     hipStream_t s = (hipStream_t)stream;
     if (dtype < 0 || dtype > 2 || rows < 0 || cols < 0 || block_size <= 0) return BFPQ_E_ARG;
@@ -1718,6 +1894,19 @@ int bfpq_quantize_threshold(const void* in, void* out_deq, void* out_codes, int8
         a.mant_bits = mant_bits; a.N = 0; a.code_bits = code_bits;
         a.force_slow = mant_bits > (dtype == BFPQ_F32 ? 24 : (dtype == BFPQ_F16 ? 11 : 8));
         a.sel = (const bfpq_select_state*)state; a.tie_counts = counts; a.tie_base = tie_base;
+        a.unit_status = nullptr; a.unit_error = nullptr;
+        if (onepass) {
+            // tie_ws doubles as the unit status array (8 B per unit of 2048 items <= the 4 B per 64 items it was sized for)
+            // and, in the unranked case, as a harmless target of the multi-pass kernel's tie reads
+            const int64_t n_units = (a.n_items + 2047) / 2048;
+            bfpq_select_state* st = (bfpq_select_state*)const_cast<void*>(state);
+            a.unit_status = reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(counts));
+            a.unit_error = reinterpret_cast<int*>(&st->reserved[1]);
+            if (!status_prepared) {
+                const hipError_t me = hipMemsetAsync(a.unit_status, 0, sizeof(unsigned long long) * (size_t)n_units, s);
+                if (me != hipSuccess) return (int)me;
+            }
+        }
         if (dtype == BFPQ_F32) return launch_fused_threshold<BFPQ_F32>(a, s);
         if (dtype == BFPQ_F16) return launch_fused_threshold<BFPQ_F16>(a, s);
         return launch_fused_threshold<BFPQ_BF16>(a, s);

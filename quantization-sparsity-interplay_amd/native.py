@@ -22,6 +22,11 @@ DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 EXP_WIN_ENTRIES = 320
 NM4_LUT_ENTRIES = 729
 NM8_LUT_ENTRIES = 1 << 24
+# Single-device unstructured s->q through bfpq_quantize_threshold_onepass (units in registers/LDS + decoupled look-back for the
+# tie ranks, no tie-count pass).  Bit-identical to the multi-pass route (tested), but measured a wash on MI355X ([5120,5120]
+# bf16: 61.9 vs 64.5 us; [13824,5120]: 129 vs 125 us) and it is a spin-wait kernel, so it is opt-in; the default stays the
+# multi-pass route (tie count + chunk sums + scan + apply as separate launches), which is also what the multi-GPU path uses.
+ONEPASS_UNSTRUCTURED = False
 USE_NM8_TABLE = True               # False: N:8 groups with straddling ties replay nth_element in the kernel (tests)
 SELECT_STATE_BYTES = 64
 SELECT_HIST_BINS = 32768
@@ -67,6 +72,8 @@ def load_library():
         L.bfpq_exp_window_host.argtypes = [i32, vp]
         L.bfpq_nm4_lut_host.argtypes = [i32, vp]
         L.bfpq_nm8_lut_host.argtypes = [i32, vp]
+        L.bfpq_quantize_threshold_onepass.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, dbl, i32, u64, vp, vp, vp, i32, vp]
+        L.bfpq_select_hist_prepare.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp]
         L.bfpq_compact24.argtypes = [vp, vp, vp, i64, vp, vp]
         L.bfpq_expand24.argtypes = [vp, vp, vp, i64, vp]
         L.bfpq_nm_prune_mask_host.argtypes = [vp, i32, i32]
@@ -90,7 +97,7 @@ def load_library():
         L.bfpq_hbfp_linear_decode.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
         L.bfpq_hbfp_linear_tiled_ok.argtypes = [i64, i64]
         L.bfpq_hbfp_linear_decode_tiled.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
-        for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
+        for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_quantize_threshold_onepass", "bfpq_select_hist_prepare", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
                      "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan", "bfpq_tie_count",
                      "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize", "bfpq_hbfp_linear_slices",
                      "bfpq_hbfp_linear_decode", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled"):
@@ -99,7 +106,7 @@ def load_library():
         return _lib
 
 
-EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24",
+EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_threshold_onepass", "bfpq_select_hist_prepare",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
                     "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan",
                     "bfpq_tie_count", "bfpq_threshold_apply", "bfpq_quantize_threshold")
@@ -265,7 +272,18 @@ def select_threshold(t, k, ws, allreduce=None):
     code = DTYPE_CODE[src.dtype]
     with torch.cuda.device(src.device):
         st = _stream(src)
+        ws.prepared_for = None
         for p in range(L.bfpq_select_passes(code)):       # ws.hist is zero on entry; every scan leaves it zeroed again
+            if p == 0 and allreduce is None and ONEPASS_UNSTRUCTURED:
+                # single device: the first histogram launch also zeroes the unit status words of the one-pass apply
+                tie = ws.tie_ws(src.numel(), code)
+                check(L.bfpq_select_hist_prepare(_ptr(src), src.numel(), code, p, _ptr(ws.state), _ptr(ws.hist), _ptr(tie), st),
+                      "bfpq_select_hist_prepare")
+                ws.prepared_for = (src.numel(), code)
+                if allreduce is not None:
+                    allreduce(ws.hist)
+                check(L.bfpq_select_scan(code, p, _ptr(ws.state), _ptr(ws.hist), int(k), st), "bfpq_select_scan")
+                continue
             check(L.bfpq_select_hist(_ptr(src), src.numel(), code, p, _ptr(ws.state), _ptr(ws.hist), st), "bfpq_select_hist")
             if allreduce is not None:
                 allreduce(ws.hist)
@@ -295,7 +313,9 @@ def quantize_threshold(t, ws, block_size, mant_bits, epsilon, want_deq=True, cod
     dev = src.device
     with torch.cuda.device(dev):
         st = _stream(src)
-        tie_base = _tie_ranks(src, code, ws, exchange_ties, st)
+        fused = L.bfpq_is_fused(rows, cols, code, int(block_size), 0, 0)
+        onepass = bool(fused) and exchange_ties is None and ONEPASS_UNSTRUCTURED and src.data_ptr() % 16 == 0
+        tie_base = None if onepass else _tie_ranks(src, code, ws, exchange_ties, st)
         deq = (out if out is not None else torch.empty_like(src)) if want_deq else None
         codes = exps = None
         if code_bits:
@@ -303,7 +323,18 @@ def quantize_threshold(t, ws, block_size, mant_bits, epsilon, want_deq=True, cod
             codes = torch.empty(shape, dtype={4: torch.uint8, 8: torch.int8, 16: torch.int16}[code_bits], device=dev)
         if want_exp:
             exps = torch.empty((rows, (cols + block_size - 1) // block_size), dtype=torch.int8, device=dev)
-        fused = L.bfpq_is_fused(rows, cols, code, int(block_size), 0, 0)
+        if onepass and (deq is None or deq.data_ptr() % 16 == 0) and (codes is None or codes.data_ptr() % 16 == 0):
+            # single device, regular shape: no tie-count pass -- units in registers + decoupled look-back
+            tie = ws.tie_ws(src.numel(), code)
+            prepared = 1 if getattr(ws, "prepared_for", None) == (src.numel(), code) else 0
+            ws.prepared_for = None
+            check(L.bfpq_quantize_threshold_onepass(_ptr(src), _ptr(deq), _ptr(codes), _ptr(exps), rows, cols, code, int(block_size),
+                                                    int(mant_bits), float(epsilon), int(code_bits), int(stoch_seed),
+                                                    _ptr(exp_window_dev(src.dtype, dev)), _ptr(ws.state), _ptr(tie), prepared, st),
+                  "bfpq_quantize_threshold_onepass")
+            return deq, codes, exps
+        if onepass:                                            # (an unaligned output view: the multi-pass route after all)
+            tie_base = _tie_ranks(src, code, ws, exchange_ties, st)
         scratch = torch.empty_like(src) if (not fused and deq is None) else None
         check(L.bfpq_quantize_threshold(_ptr(src), _ptr(deq), _ptr(codes), _ptr(exps), rows, cols, code, int(block_size),
                                         int(mant_bits), float(epsilon), int(code_bits), int(stoch_seed),

@@ -736,3 +736,32 @@ def test_dist_paths_with_the_native_engine_on_rccl():
         assert torch.equal(codes, c1) and torch.equal(exps, e1)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dname", ["bf16", "f16", "f32"])
+def test_unstructured_onepass_equals_multipass(dname):
+    """single-device unstructured s->q: the one-pass kernel (units in registers/LDS + decoupled look-back for the flat-order
+    tie ranks) must give the bits of the multi-pass route (tie count + chunk sums + scan + apply) -- small and large tensors
+    (more units than workgroups: several rounds of look-back), tie-heavy inputs, every sparsity fraction.  The multi-pass
+    route itself is held to the oracle's contract by the cfg4 / G5 tests above."""
+    dt = DT[dname]
+    shapes = [(4, 64), (64, 256), (257, 1024), (2048, 4096), (5120, 5120)]
+    default = native.ONEPASS_UNSTRUCTURED
+    try:
+        for rows, cols in shapes:
+            for tag in ("real", "coarse"):
+                xc = synth(rows, cols, dt, 1.0, seed=rows + cols)
+                if tag == "coarse":
+                    xc = (xc.float() * 4).round().div(4).to(dt)                     # ~20 distinct magnitudes: huge tie classes
+                x = xc.to(DEV)
+                for frac in ((0.5,) if rows > 1000 and tag == "real" else (0.1, 0.5, 0.9)):
+                    c = cfg(w_sparsity=True, sparsity_mode='unstructured', sparsity_frac=frac, first='s')
+                    native.ONEPASS_UNSTRUCTURED = True
+                    a = bfp_ops.float_to_bfp_blocked(x, **c, identifier='w')
+                    err = int(bfp_ops._workspace(x.device).state[7].item())
+                    native.ONEPASS_UNSTRUCTURED = False
+                    b = bfp_ops.float_to_bfp_blocked(x, **c, identifier='w')
+                    assert err == 0, "a look-back spin hit its cap"
+                    assert_bits_equal(bits(a), bits(b), dt, f"one-pass vs multi-pass [{rows},{cols}] {tag} frac={frac}")
+    finally:
+        native.ONEPASS_UNSTRUCTURED = default
