@@ -26,7 +26,7 @@ NM8_LUT_ENTRIES = 1 << 24
 # tie ranks, no tie-count pass).  Bit-identical to the multi-pass route (tested), but measured a wash on MI355X ([5120,5120]
 # bf16: 61.9 vs 64.5 us; [13824,5120]: 129 vs 125 us) and it is a spin-wait kernel, so it is opt-in; the default stays the
 # multi-pass route (tie count + chunk sums + scan + apply as separate launches), which is also what the multi-GPU path uses.
-ONEPASS_UNSTRUCTURED = False
+ONEPASS_UNSTRUCTURED = os.environ.get("BFPQ_ONEPASS", "0") == "1"
 USE_NM8_TABLE = True               # False: N:8 groups with straddling ties replay nth_element in the kernel (tests)
 SELECT_STATE_BYTES = 64
 SELECT_HIST_BINS = 32768
