@@ -38,7 +38,7 @@ CASES = [
     ("cfg5 ViT-L act [8x197,1024] f32 HBFP8 b16 dense (identifier in)", 8 * 197, 1024, "f32", 8, dict(mant_bits=7, block_size=16, N=1, M=4, w_sparsity=True, _ident='in')),
     ("down_proj bf16 HBFP4 b64 4:8 s (N:8 in the flat kernel)", 4096, 11008, "bf16", 4, dict(w_sparsity=True, N=4, M=8)),
     ("down_proj bf16 HBFP4 b64 4:8 q, tie-heavy input (every group through the N:8 rank table)", 4096, 11008, "bf16", 4, dict(w_sparsity=True, N=4, M=8, first='q', _prequant=True)),
-    ("general path: down_proj f32 HBFP4 b64 4:8 s (k_nm_rows + flat quantize)", 4096, 11008, "f32", 8, dict(w_sparsity=True, N=4, M=8)),
+    ("down_proj f32 HBFP4 b64 4:8 s (N:8 in the flat kernel, DPP pair exchange)", 4096, 11008, "f32", 8, dict(w_sparsity=True, N=4, M=8)),
     ("general path: [4096,11000] bf16 HBFP4 b64 dense (ragged rows)", 4096, 11000, "bf16", 4, dict()),
     ("stochastic rounding: down_proj bf16 HBFP4 2:4 s (fp32 out, as the reference returns)", 4096, 11008, "bf16", 6, dict(w_sparsity=True, rounding_mode='stoc')),
     ("int8 per-row: down_proj bf16 weights (fp32 out)", 4096, 11008, "bf16", 6, dict(sparsity_num_format='int', mant_bits=8)),

@@ -310,11 +310,53 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
                 auto m = [](uint32_t pr) { return ((pr & 1u) ? 0u : 0xffffu) | ((pr & 2u) ? 0u : 0xffff0000u); };
                 d0 &= m(prune); d1 &= m(prune >> 2); d2 &= m(prune >> 4); d3 &= m(prune >> 6);
             }
+        } else if constexpr (NM == 8 && VEC == 4) {
+            // fp32: a group of 8 is two adjacent lane items (even lane: elements 0-3, odd lane: 4-7; item parity = lane
+            // parity because the sweep stride is a multiple of 256).  The partner's four keys come over by DPP (swap of
+            // adjacent lanes); every lane then counts, for its own four elements, the smaller and the equal keys among
+            // all eight, and the group decides as in the 16-bit path: certainly pruned / certainly kept / look the weak
+            // ordering up (or replay nth_element) when ties straddle the cut.
+            auto swp = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); };
+            const uint32_t own[4] = {mag_key<DT>(d0), mag_key<DT>(d1), mag_key<DT>(d2), mag_key<DT>(d3)};
+            const uint32_t oth[4] = {swp(own[0]), swp(own[1]), swp(own[2]), swp(own[3])};
+            const bool odd = (threadIdx.x & 1) != 0;
+            const int P = 8 - a.N;
+            uint32_t less4 = 0, prune = 0;
+            bool amb = false;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                int less = 0, eq = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    less += (own[j] < own[i]) + (oth[j] < own[i]);
+                    eq += (own[j] == own[i]) + (oth[j] == own[i]);
+                }
+                less4 |= (uint32_t)less << (3 * i);
+                if (less + eq <= P) prune |= 1u << i;
+                else if (less < P) amb = true;
+            }
+            const uint32_t amb_group = (uint32_t)amb | swp((uint32_t)amb);
+            if (amb_group) {
+                const uint32_t other_less = swp(less4);
+                const uint32_t lo = odd ? other_less : less4, hi = odd ? less4 : other_less;   // elements 0-3 | 4-7
+                uint32_t mask8;
+                if (a.nm_lut) mask8 = a.nm_lut[lo | (hi << 12)];
+                else {
+                    KvView view{s_kv + threadIdx.x, kThreads};
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        view.set(odd ? 4 + i : i, ((uint64_t)own[i] << 8) | (uint64_t)(odd ? 4 + i : i));
+                        view.set(odd ? i : 4 + i, ((uint64_t)oth[i] << 8) | (uint64_t)(odd ? i : 4 + i));
+                    }
+                    mask8 = (uint32_t)nm_prune_mask(view, a.N, 8);
+                }
+                prune = odd ? (mask8 >> 4) & 0xfu : mask8 & 0xfu;
+            }
+            d0 = (prune & 1u) ? 0u : d0; d1 = (prune & 2u) ? 0u : d1; d2 = (prune & 4u) ? 0u : d2; d3 = (prune & 8u) ? 0u : d3;
         } else if constexpr (NM == 8) {
             // one lane item = one group of 8 (16-bit dtypes).  Count, per element, the smaller and the equal keys (28 pair
             // comparisons in registers): less + equal <= P -> certainly pruned, less >= P -> certainly kept; only a group
             // whose ties straddle the cut needs the reference's tie order (libstdc++ nth_element replay on an LDS column)
-            static_assert(VEC == 8, "N:8 in the flat kernel is for 16-bit dtypes");
             // Packed: the item's four dwords ARE the key pairs.  c = clamp(k_i - k_j, -1, 1) for two pairs per instruction;
             // per element S = sum_j c = 2 less + eq - 8 and A = sum_j c^2 = 8 - eq, so
             //   pruned  <=> less + eq <= P <=> S - A <= 2P - 16,      certainly kept <=> less >= P <=> S + A >= 2P
@@ -1477,15 +1519,18 @@ int launch_fused_threshold(const FusedArgs& a, hipStream_t s)
 template <int DT, bool SFIRST, bool STOCH>
 int launch_fused_nm8(const FusedArgs& a, hipStream_t s)
 {
-    if constexpr (Traits<DT>::VEC == 8) {
-        const dim3 grid(grid_for(a.n_items)), block(kThreads);
-        const bool deq_only = a.out_deq && !a.out_codes && !a.out_exp;
-        if constexpr (STOCH) hipLaunchKernelGGL((k_fused_flat<DT, 8, SFIRST, true, -1, false>), grid, block, 0, s, a);
-        else if (deq_only && a.lpb == 8) hipLaunchKernelGGL((k_fused_flat<DT, 8, SFIRST, false, 8, true>), grid, block, 0, s, a);
+    const dim3 grid(grid_for(a.n_items)), block(kThreads);
+    const bool deq_only = a.out_deq && !a.out_codes && !a.out_exp;
+    if constexpr (STOCH) hipLaunchKernelGGL((k_fused_flat<DT, 8, SFIRST, true, -1, false>), grid, block, 0, s, a);
+    else if constexpr (Traits<DT>::VEC == 8) {
+        if (deq_only && a.lpb == 8) hipLaunchKernelGGL((k_fused_flat<DT, 8, SFIRST, false, 8, true>), grid, block, 0, s, a);
         else if (deq_only) hipLaunchKernelGGL((k_fused_flat<DT, 8, SFIRST, false, -1, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((k_fused_flat<DT, 8, SFIRST, false, -1, false>), grid, block, 0, s, a);
-        return (int)hipGetLastError();
-    } else return BFPQ_E_UNSUPPORTED;
+    } else {
+        if (deq_only) hipLaunchKernelGGL((k_fused_flat<DT, 8, SFIRST, false, -1, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((k_fused_flat<DT, 8, SFIRST, false, -1, false>), grid, block, 0, s, a);
+    }
+    return (int)hipGetLastError();
 }
 
 template <int DT, bool STOCH>
@@ -1553,7 +1598,7 @@ bool fused_shape_ok(int64_t rows, int64_t cols, int dtype, int block_size, int N
     const int vec = dtype_vec(dtype);
     const int64_t numel = rows * cols;
     if (numel == 0 || numel % vec != 0) return false;
-    if (!(M == 0 || M == 2 || M == 4 || (M == 8 && vec == 8))) return false;   // N:8 = one 16-byte item of a 16-bit dtype
+    if (!(M == 0 || M == 2 || M == 4 || M == 8)) return false;   // N:8 = one 16-byte item of a 16-bit dtype, two adjacent items of fp32
     if (M != 0 && cols % M != 0) return false;
     if (block_size == 0) return M != 0;                              // sparsify only
     if (cols % block_size != 0 || block_size % vec != 0) return false;

@@ -322,7 +322,7 @@ def test_packed_linear_any_token_count(T):
     assert float(err) < 1.2e-2, float(err)                              # bf16 output (+ bf16 bias add) rounding
 
 
-@pytest.mark.parametrize("dname", ["bf16", "f16"])
+@pytest.mark.parametrize("dname", ["bf16", "f16", "f32"])
 def test_nm8_in_the_flat_kernel(dname):
     """N:8 on 16-bit dtypes runs inside the fused kernel (one lane item = one group): counted decision in registers,
     nth_element replay only when ties straddle the cut.  Real-valued rows (no straddling ties), coarse-grid rows (ties
@@ -364,8 +364,8 @@ def test_nm8_in_the_flat_kernel(dname):
         assert_bits_equal(bits(got), bits(O.float_to_bfp_blocked(coarse, **c, identifier='w')), dt, "4:8 replay path")
     finally:
         native.USE_NM8_TABLE = True
-    # the fp32 tensor still takes the general kernel (a group spans two lane items) and must agree as well
-    x32 = synth(64, 512, torch.float32)
+    # fp32 through the same kernel (a group spans two adjacent lane items), odd row count x ragged last sweep
+    x32 = synth(67, 512, torch.float32)
     c = cfg(mant_bits=3, block_size=64, w_sparsity=True, N=4, M=8)
     assert_bits_equal(bits(bfp_ops.float_to_bfp_blocked(x32.to(DEV), **c, identifier='w')),
                       bits(O.float_to_bfp_blocked(x32, **c, identifier='w')), torch.float32, "f32 4:8")

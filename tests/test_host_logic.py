@@ -158,7 +158,7 @@ def test_is_fused_dispatch():
     assert L.bfpq_is_fused(4096, 1024, native.F32, 16, 1, 4) == 1          # cfg 5
     assert L.bfpq_is_fused(5, 100, native.BF16, 64, 2, 4) == 0             # ragged rows
     assert L.bfpq_is_fused(64, 256, native.BF16, 64, 4, 8) == 1            # N:8 on a 16-bit dtype: one lane item per group
-    assert L.bfpq_is_fused(64, 256, native.F32, 64, 4, 8) == 0             # fp32 group of 8 spans two lane items -> general path
+    assert L.bfpq_is_fused(64, 256, native.F32, 64, 4, 8) == 1             # fp32: a group of 8 = two adjacent lane items (DPP exchange)
     assert L.bfpq_is_fused(64, 256, native.BF16, 64, 4, 16) == 0           # M = 16 -> general path
     assert L.bfpq_is_fused(64, 256, native.BF16, 48, 0, 0) == 0            # 6 lanes per block
 
