@@ -716,7 +716,11 @@ def test_dist_paths_with_the_native_engine_on_rccl():
     from quantization_sparsity_interplay_amd import dist as D
     if dist.is_initialized():
         pytest.skip("a process group already exists in this process")
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1, device_id=torch.device(DEV))
+    import socket
+    with socket.socket() as sk:                                         # a free port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device(DEV))
     try:
         xc = synth(256, 1024, torch.bfloat16)
         x = xc.to(DEV)
