@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BFPQ_VERSION 1
+#define BFPQ_VERSION 2
 
 enum { BFPQ_F32 = 0, BFPQ_F16 = 1, BFPQ_BF16 = 2 };
 
@@ -108,58 +108,52 @@ int bfpq_nm_sparsify(const void* in_dev, void* out_dev, int64_t rows, int64_t co
                      int N, int M, const uint8_t* nm4_lut_dev, void* stream);
 
 /* ---- unstructured magnitude pruning (replaces _unstructured_sparsity, bfp_ops.py:61-71) -------
- * Exact global k-th smallest |v| by radix select on the magnitude bit pattern, in steps so that a
- * multi-GPU caller can all-reduce between them (row-sharded tensors share one threshold):
- *   1. for pass p in [0, bfpq_select_passes(dtype)):
- *        bfpq_select_hist(...)      per-device histogram of the current digit  -> hist_dev
- *        [all-reduce hist_dev across ranks]
- *        bfpq_select_scan(..., k)   picks the digit, updates state_dev (pass 0 initialises it with k)
- *   2. bfpq_tie_count(...)          elements equal to the threshold per chunk  -> tie_ws_dev
- *        [multi-GPU: exchange per-rank totals, pass the sum of lower ranks as tie_base]
- *   3. bfpq_threshold_apply(...)    zeroes every |v| < tau and the first `need` (in flat index
- *                                   order, lower ranks first) of the |v| == tau
- * state_dev: BFPQ_SELECT_STATE_BYTES bytes, hist_dev: BFPQ_SELECT_HIST_BINS uint32 (zero before the
- * first use; bfpq_select_scan leaves it zeroed again), tie_ws_dev: bfpq_tie_workspace_elems(numel,
- * dtype) uint32 (after bfpq_tie_count: ties per 64-lane-item tile, and an exclusive prefix over chunks
- * of 64 tiles; the local total is left in state_dev->reserved[0] for the multi-GPU exchange).
- * k is the global prune count int(numel_global * frac) (bfp_ops.py:66).
+ * Exact global k-th smallest |v| by radix select on the magnitude bit pattern, then "zero everything below the
+ * threshold tau and the first `need` (flat index order, lower ranks first) of the elements equal to it".
+ * THREE launches for a 16-bit dtype (fp32: three histogram/resolve pairs, then the apply):
+ *   for pass p in [0, bfpq_select_passes(dtype)):
+ *     1. bfpq_select_hist(...)       histogram of the current digit of this device's elements; on the last pass also
+ *                                    per-segment windows of it -> ws_dev
+ *     2. bfpq_select_resolve(...)    picks the digit (pass 0 starts the selection with k); on the last pass leaves tau,
+ *                                    need, ties and the tie bookkeeping of this device's slab in ws_dev
+ *   Single device: pass hist_dev = NULL / hist_all_dev = NULL -- the launches use histogram buffers inside ws_dev, which
+ *   must be ZERO before the first call; the apply launch (step 3) clears them again.  A select that is NOT followed by an
+ *   apply (diagnostics) must be followed by bfpq_select_reset before the next select.
+ *   Multi-GPU: give bfpq_select_hist a caller-owned hist_dev (BFPQ_SELECT_HIST_COPIES x BFPQ_SELECT_HIST_ENTRIES uint32, zero
+ *   on entry), ALL-GATHER the per-rank buffers into hist_all_dev [n_ranks][BFPQ_SELECT_HIST_COPIES][BFPQ_SELECT_HIST_ENTRIES] -- the one exchange of the path: the
+ *   per-rank counts of the threshold bin also tell every rank how many ties lower ranks hold -- and let
+ *   bfpq_select_resolve clear the local histogram for its next use (zero_hist_dev = hist_dev).
+ *   3. bfpq_threshold_apply(...) or bfpq_quantize_threshold(...)   prune (and quantize) in one pass
+ * ws_dev: BFPQ_SELECT_WS_BYTES bytes, zeroed once, 16-byte aligned; it begins with a bfpq_select_state.
+ * k is the GLOBAL prune count int(numel_global * frac) (bfp_ops.py:66); numel_global < 2^32.
  * Tie positions: the reference's are those of a sequential introselect over the whole tensor and
- * are not reproduced; threshold, count and every element outside the tie class are. */
+ * are not reproduced; threshold, count and every element outside the tie class are.
+ * How ties are ranked without a rank per tile: csrc/bfpq_kernels.hip, block comment at "Unstructured pruning". */
 #define BFPQ_SELECT_STATE_BYTES 64
-#define BFPQ_SELECT_HIST_BINS 32768
+#define BFPQ_SELECT_MAX_SEGMENTS 256
+#define BFPQ_SELECT_WINDOW_BINS 2048
+#define BFPQ_SELECT_MAX_PIECES 4096
+#define BFPQ_SELECT_HIST_ENTRIES (32768 + 256)   /* fine bins, then (16-bit dtypes) 256 coarse bins of 128 */
+#define BFPQ_SELECT_HIST_COPIES 8                /* a device accumulates into 8 copies (cuts the contention of the flush) */
+#define BFPQ_SELECT_WS_BYTES (BFPQ_SELECT_STATE_BYTES + 4 * (3 * BFPQ_SELECT_HIST_COPIES * BFPQ_SELECT_HIST_ENTRIES + 2 * BFPQ_SELECT_MAX_SEGMENTS + \
+                              BFPQ_SELECT_MAX_PIECES + BFPQ_SELECT_MAX_SEGMENTS * BFPQ_SELECT_WINDOW_BINS))
 
 int bfpq_select_passes(int dtype);
-int64_t bfpq_tie_workspace_elems(int64_t numel, int dtype);
-int bfpq_select_hist(const void* in_dev, int64_t numel, int dtype, int pass,
-                     const void* state_dev, uint32_t* hist_dev, void* stream);
-int bfpq_select_scan(int dtype, int pass, void* state_dev, uint32_t* hist_dev, int64_t k, void* stream);
-int bfpq_tie_count(const void* in_dev, int64_t numel, int dtype, void* state_dev,
-                   uint32_t* tie_ws_dev, void* stream);
-int bfpq_threshold_apply(const void* in_dev, void* out_dev, int64_t numel, int dtype,
-                         const void* state_dev, const uint32_t* tie_ws_dev,
-                         const int64_t* tie_base_dev /* nullable: 0 */, void* stream);
+int64_t bfpq_select_ws_bytes(void);
+int bfpq_select_hist(const void* in_dev, int64_t numel, int dtype, int pass, int64_t k, int64_t numel_global,
+                     void* ws_dev, uint32_t* hist_dev, void* stream);
+int bfpq_select_resolve(const void* in_dev, int64_t numel, int dtype, int pass, int64_t k,
+                        const uint32_t* hist_all_dev /* [n_ranks][COPIES][ENTRIES] */, int n_ranks, int rank,
+                        void* ws_dev, uint32_t* zero_hist_dev, void* stream);
+int bfpq_select_reset(void* ws_dev, void* stream);
+int bfpq_threshold_apply(const void* in_dev, void* out_dev, int64_t numel, int dtype, void* ws_dev, void* stream);
 /* step 3 fused with the quantizer: out = Q(S_threshold(in)) in one pass over the tensor (first == 's',
  * bfp_ops.py:141-144 with sparsity_mode 'unstructured'); same outputs / tables / fallbacks as
  * bfpq_quantize_nm (scratch_dev only when the shape needs the two-launch path and out_deq_dev is NULL). */
 int bfpq_quantize_threshold(const void* in_dev, void* out_deq_dev, void* out_codes_dev, int8_t* out_exp_dev,
                             int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits, double epsilon,
                             int code_bits, uint64_t stoch_seed, const uint8_t* exp_win_dev,
-                            const void* state_dev, const uint32_t* tie_ws_dev, const int64_t* tie_base_dev,
-                            void* scratch_dev, void* stream);
-
-/* The same result in ONE pass over the tensor and without bfpq_tie_count (single device, fused shapes only, else
- * BFPQ_E_UNSUPPORTED): workgroups hold units of 2048 lane items in registers, count their threshold ties and learn the
- * ties of all earlier units by decoupled look-back on packed (flag, count) words in tie_ws_dev (bfpq_tie_workspace_elems
- * entries, 16-byte aligned).  Same flat-index-first tie rule, bit-identical output.
- * state_dev->reserved[1] is set to 1 if a look-back spin hit its cap (never in a healthy run). */
-int bfpq_quantize_threshold_onepass(const void* in_dev, void* out_deq_dev, void* out_codes_dev, int8_t* out_exp_dev,
-                                    int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits, double epsilon,
-                                    int code_bits, uint64_t stoch_seed, const uint8_t* exp_win_dev,
-                                    void* state_dev, uint32_t* tie_ws_dev, int status_prepared, void* stream);
-/* bfpq_select_hist that also zeroes, for free, the unit status words the one-pass apply of the same tensor needs (pass
- * status_prepared = 1 to bfpq_quantize_threshold_onepass then; with 0 it zeroes them itself with a memset) */
-int bfpq_select_hist_prepare(const void* in_dev, int64_t numel, int dtype, int pass, const void* state_dev, uint32_t* hist_dev,
-                             uint32_t* tie_ws_dev, void* stream);
+                            void* ws_dev, void* scratch_dev, void* stream);
 
 /* ---- 'int' per-channel format (replaces _quantize's 'int' branch, bfp_ops.py:111-120, i.e.
  * int_ops.Quantizer.configure/find_params/quantize with the defaults perchannel=True, sym=True) -------
@@ -213,17 +207,19 @@ int bfpq_hbfp_linear_decode_tiled(const void* wtiles_dev, const void* wexpt_dev,
                                   void* out_dev, int64_t T, int64_t N, int64_t K,
                                   int out_dtype, int w_mant_bits, int x_mant_bits, void* stream);
 
-/* layout of state_dev as read back by a host that wants tau / counts (all little-endian) */
+/* the first BFPQ_SELECT_STATE_BYTES of ws_dev, as read back by a host that wants tau / counts (little-endian) */
 typedef struct bfpq_select_state {
     uint32_t prefix;      /* magnitude bits decided so far (high digits)                         */
     uint32_t prefix_mask; /* which bits of prefix are decided                                    */
     int64_t k_rem;        /* how many of the elements matching prefix are still to be pruned     */
     uint32_t tau;         /* after the last pass: magnitude bit pattern of the threshold         */
     uint32_t done;        /* 1 after the last pass                                               */
-    int64_t need;         /* how many elements equal to tau get pruned                           */
-    int64_t ties;         /* how many elements equal tau in total                                */
-    int64_t k;            /* the k given to bfpq_select_scan                                     */
-    int64_t reserved[2];
+    int64_t need;         /* how many elements equal to tau get pruned (over all ranks)          */
+    int64_t ties;         /* how many elements equal tau in total (over all ranks)               */
+    int64_t k;            /* the k given to bfpq_select_resolve                                  */
+    int64_t tie_base;     /* elements equal to tau held by lower ranks                           */
+    uint32_t flags;       /* bit 0: per-piece tie counts of the cut segment are valid; bit 1: the histograms inside ws_dev were used */
+    uint32_t reserved;
 } bfpq_select_state;
 
 #ifdef __cplusplus

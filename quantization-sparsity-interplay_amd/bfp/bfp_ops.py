@@ -93,10 +93,13 @@ _select_ws = {}
 
 
 def _workspace(device):
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    """select workspace of the current stream of `device` (the launches of one call talk through it, so two streams
+    must not share one)"""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
     ws = _select_ws.get(key)
     if ws is None:
-        ws = _select_ws[key] = native.SelectWorkspace(device)
+        ws = _select_ws[key] = native.SelectWorkspace(torch.device("cuda", idx))
     return ws
 
 

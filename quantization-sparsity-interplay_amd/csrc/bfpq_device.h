@@ -1,0 +1,445 @@
+// bfpq_device.h -- device helpers shared by the translation units of libbfpq.so: streaming loads/stores, packed 16-bit
+// VALU spellings, wave scans, the bookkeeping of the unstructured path (segments, pieces, the ranked region), and the
+// small host helpers of the launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+#include "bfpq.h"
+#include "bfpq_common.h"
+
+extern "C" __attribute__((visibility("hidden"))) int bfpq_g_max_grid;    // bfpq_kernels.hip (bfpq_tune)
+
+namespace bfpq_dev {
+using namespace bfpq;
+
+#ifndef BFPQ_MAXGRID
+#define BFPQ_MAXGRID 1024          // 256 CUs x 4 workgroups, grid-stride beyond that (A/B over 5 shapes: 1024 best or tied)
+#endif
+#ifndef BFPQ_NT
+#define BFPQ_NT 1                  // non-temporal loads/stores on the once-touched streams (A/B: +6..8 %)
+#endif
+constexpr int kThreads = 256;
+#define kMaxGrid bfpq_g_max_grid
+
+__device__ __forceinline__ uint4 stream_load(const uint4* p)
+{
+#if BFPQ_NT
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void stream_store(uint4* p, uint4 v)
+{
+#if BFPQ_NT
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const u4v w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<u4v*>(p));
+#else
+    *p = v;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+typedef short short2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t cmp3(uint32_t a, uint32_t b) { return (uint32_t)(a > b) + (uint32_t)(a >= b); }
+
+// signature index of one group of 4 magnitude keys (see bfpq_nm4_lut_host): sum_p c_p 3^p, c in {0,1,2}
+__device__ __forceinline__ uint32_t nm4_index(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3)
+{
+    // keys < 2^31: the signed difference clamped to [-1,1] is the 3-way comparison
+    auto c = [](uint32_t a, uint32_t b) { const int d = (int)a - (int)b; return d < -1 ? -1 : (d > 1 ? 1 : d); };
+    return (uint32_t)(364 + c(k0, k1) + 3 * c(k0, k2) + 9 * c(k0, k3) + 27 * c(k1, k2) + 81 * c(k1, k3) + 243 * c(k2, k3));
+}
+
+// keep-mask of one group of 2 (keep 1): stable insertion sort of two -> index 0 goes on a tie
+__device__ __forceinline__ uint32_t nm2_keep(uint32_t k0, uint32_t k1, int N)
+{
+    if (N >= 2) return 3u;
+    return (k1 < k0) ? 1u : 2u;
+}
+
+// packed 16-bit VALU ops, spelled out: hipcc scalarises a clamp written with vector builtins into
+// per-half v_cmp / v_cndmask chains (seen in the ISA of the first version of this kernel)
+__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_max_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t pk_mad_i16(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ uint32_t pk_add_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_add_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// same with the constant operand in an SGPR (one scalar operand per VALU instruction is allowed)
+__device__ __forceinline__ uint32_t pk_ashr_i16_s(uint32_t a, uint32_t sh) { uint32_t d; asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(d) : "s"(sh), "v"(a)); return d; }
+__device__ __forceinline__ uint32_t pk_max_i16_s(uint32_t a, uint32_t k) { uint32_t d; asm("v_pk_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k)); return d; }
+__device__ __forceinline__ uint32_t pk_min_i16_s(uint32_t a, uint32_t k) { uint32_t d; asm("v_pk_min_i16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k)); return d; }
+__device__ __forceinline__ uint32_t pk_mad_i16_s(uint32_t a, uint32_t k, uint32_t c) { uint32_t d; asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c)); return d; }
+
+// max over the 2^n adjacent lanes that share one block, by DPP where the ISA has a pattern for it
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_max(uint32_t v)
+{
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+    return o > v ? o : v;
+}
+__device__ __forceinline__ uint32_t shfl_max(uint32_t v, int o)
+{
+    const uint32_t other = (uint32_t)__shfl_xor((int)v, o, 64);
+    return other > v ? other : v;
+}
+// LPBT > 0: lanes per block known at compile time; LPBT < 0: runtime value lpb
+template <int LPBT> __device__ __forceinline__ uint32_t group_max(uint32_t v, int lpb)
+{
+    const int n = LPBT > 0 ? LPBT : lpb;
+    if (n >= 2) v = dpp_max<0xB1>(v);        // quad_perm [1,0,3,2]
+    if (n >= 4) v = dpp_max<0x4E>(v);        // quad_perm [2,3,0,1]
+    if (n >= 8) v = dpp_max<0x141>(v);       // row_half_mirror: the other quad of the 8-lane half
+    if (n >= 16) v = dpp_max<0x140>(v);      // row_mirror: the other half of the 16-lane row
+    if (n >= 32) v = shfl_max(v, 16);
+    if (n >= 64) v = shfl_max(v, 32);
+    return v;
+}
+
+struct SelWs;
+struct FusedArgs {
+    const void* in;
+    void* out_deq;
+    void* out_codes;
+    int8_t* out_exp;
+    int64_t n_items;          // numel / VEC
+    const uint8_t* exp_win;   // global, BFPQ_EXP_WIN_ENTRIES
+    const uint8_t* nm_lut;    // global, BFPQ_NM4_LUT_ENTRIES (NM == 4)
+    uint64_t seed;
+    float eps_dt;
+    int lpb;                  // lanes per block (power of two <= 64); 0 = no quantization
+    int mant_bits;
+    int N;
+    int code_bits;
+    int force_slow;           // mant_bits wider than the dtype significand: always emulate step by step
+    SelWs* selws;             // NM == -1 (global magnitude threshold): the select workspace (threshold + tie bookkeeping)
+};
+
+// wave-level inclusive scan (lane order) by DPP: row_shr 1/2/4/8 inside the rows of 16 lanes, then row_bcast15 /
+// row_bcast31 carry the row totals forward (six VALU adds; the ds_bpermute form is six LDS round trips)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+__device__ __forceinline__ int64_t uniform64(int64_t v)           // a wave-uniform value, moved to scalar registers
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v), 63);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Unstructured pruning: bookkeeping shared by the three launches (histogram, resolve, apply).
+//
+// Tie rule: of the elements EQUAL to the threshold, the first `need` in flat index order go (lower ranks
+// first on a row-sharded tensor) -- a pure function of the flat index, so a sharded run and a single-device
+// run zero the same elements.  Ranks are never materialised per tile.  Instead:
+//   * the histogram launch cuts the tensor into <= 256 flat-contiguous SEGMENTS, one workgroup each; the
+//     workgroup's private LDS histogram is, at the end, also an exact count of every magnitude inside the
+//     segment, and a 2048-bin WINDOW of it around the segment's own k-quantile is left in the workspace;
+//   * the resolve launch finds the threshold tau and reads every segment's tie count out of its window
+//     (a segment whose window does not cover tau and that holds magnitudes outside the window recounts
+//     itself: correct for any input, one extra read of that segment).  The cut -- the flat position where the
+//     cumulative tie count reaches `need` -- falls into one segment; that segment's ties are counted again per
+//     PIECE (<= 4096 pieces of whole 64-item tiles; one tile per piece up to 67 M items per tensor);
+//   * the apply launch (threshold_apply / the fused quantizer) turns the two small arrays into a REGION
+//     [rs, re) of lane items: every tile in front of it prunes all ties (compare against tau + 1), every tile
+//     behind it prunes none (compare against tau), and only the tiles inside it -- normally one -- rank their
+//     ties with a wave scan.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSelThreads = 1024;
+constexpr int kMaxSeg = BFPQ_SELECT_MAX_SEGMENTS;
+constexpr int kWinBins = BFPQ_SELECT_WINDOW_BINS;
+constexpr int kMaxPieces = BFPQ_SELECT_MAX_PIECES;
+constexpr int kFineBins = 32768, kCoarseBins = 256;
+
+struct SelWs {
+    bfpq_select_state st;
+    // the workspace's own histogram buffers (single-device use), one per radix pass; all zero between calls: the APPLY launch
+    // clears what the histogram launches of its call dirtied (see thr_setup; bfpq_select_reset after a select with no apply)
+    uint32_t hist[3][BFPQ_SELECT_HIST_COPIES][BFPQ_SELECT_HIST_ENTRIES];
+    uint32_t seg_ties[kMaxSeg];               // elements equal to tau per segment
+    uint32_t seg_win[kMaxSeg];                // first bin of the segment's window | bit 31: magnitudes outside the window exist
+    uint32_t piece_counts[kMaxPieces];        // ties per piece of the segment that holds the cut
+    uint32_t windows[kMaxSeg][kWinBins];
+};
+static_assert(sizeof(SelWs) == BFPQ_SELECT_WS_BYTES, "bfpq.h: BFPQ_SELECT_WS_BYTES");
+
+struct SegGeom { int G; int64_t L; };         // G segments of L lane items (L a multiple of 64)
+__host__ __device__ inline SegGeom seg_geom(int64_t n_items)
+{
+    SegGeom g;
+    int64_t g0 = (n_items + 2047) / 2048;
+    if (g0 < 1) g0 = 1;
+    if (g0 > kMaxSeg) g0 = kMaxSeg;
+    int64_t L = (n_items + g0 - 1) / g0;
+    L = (L + 63) / 64 * 64;
+    if (L < 64) L = 64;
+    g.L = L;
+    g.G = (int)((n_items + L - 1) / L);
+    if (g.G < 1) g.G = 1;
+    return g;
+}
+struct PieceGeom { int n; int64_t tiles_per; };
+__host__ __device__ inline PieceGeom piece_geom(int64_t seg_len_items)
+{
+    const int64_t tiles = (seg_len_items + 63) / 64;
+    PieceGeom p;
+    p.tiles_per = (tiles + kMaxPieces - 1) / kMaxPieces;
+    if (p.tiles_per < 1) p.tiles_per = 1;
+    p.n = (int)((tiles + p.tiles_per - 1) / p.tiles_per);
+    return p;
+}
+
+// exclusive prefix sum of one value per thread over the workgroup (blockDim.x a multiple of 64, <= 1024); every thread
+// gets the total.  s_part: 16 words of LDS.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_part, uint32_t* total)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    const uint32_t incl = wave_incl_scan(v);
+    __syncthreads();                                        // (s_part may still be read from the previous scan)
+    if (lane == 63) s_part[w] = incl;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+    for (int i = 0; i < nw; i++) { const uint32_t p = s_part[i]; off += i < w ? p : 0u; tot += p; }
+    *total = tot;
+    return off + incl - v;
+}
+
+// threshold state of one apply workgroup, wave-uniform
+struct ThrCtx {
+    uint32_t tau;
+    bool on;
+    int64_t rs, re;            // the region of lane items whose ties are ranked (multiples of 64, re possibly n_items)
+    uint32_t need_in;          // ties to prune inside the region, counted from its start
+    const void* in;
+    int64_t numel;
+};
+
+template <int DT, bool FAST>
+__device__ __forceinline__ void sweep_load(const void* in, int64_t item, int64_t n_items, int64_t numel, uint32_t* raw);
+
+template <int DT> __device__ __forceinline__ uint32_t count_eq(const uint32_t* raw, uint32_t tau)
+{
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < Traits<DT>::VEC; j++) c += mag_key<DT>(raw[j]) == tau;
+    return c;
+}
+
+// Region of ranked tiles for this tensor, from the workspace the resolve launch left (block-uniform result; uses
+// blockDim.x == 256 threads, >= 2 barriers).  s_part: 16 words, s_res: 8 words of LDS.
+template <int DT>
+__device__ __forceinline__ void thr_setup(ThrCtx& t, SelWs* ws, const void* in, int64_t numel, int64_t n_items,
+                                          uint32_t* s_part, uint32_t* s_res)
+{
+    const bfpq_select_state* st = &ws->st;
+    if (st->flags & 2u) {
+        // the histograms of this call have been consumed by the resolve launch: clear them for the next call
+        constexpr int NC = BFPQ_SELECT_HIST_COPIES;
+        const int i0 = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+        if constexpr (DT == BFPQ_F32) {
+            for (int i = i0; i < 3 * NC * 512; i += step)                      // passes x copies x 2048 bins
+                reinterpret_cast<uint4*>(ws->hist[i / (NC * 512)][(i / 512) % NC])[i % 512] = make_uint4(0, 0, 0, 0);
+        } else {
+            for (int i = i0; i < NC * BFPQ_SELECT_HIST_ENTRIES / 4; i += step) reinterpret_cast<uint4*>(ws->hist[0][0])[i] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    t.tau = st->tau;
+    t.on = st->k > 0;
+    t.in = in; t.numel = numel;
+    t.rs = t.re = 0; t.need_in = 0;                          // empty region at the front: no tie is pruned
+    if (!t.on) { t.tau = 0; return; }                        // (k == 0: nothing is below a threshold of 0)
+    const int64_t need = st->need, ties = st->ties;
+    if (need <= 0) return;
+    if (need >= ties) { t.rs = t.re = n_items; return; }    // every tie goes
+    const SegGeom g = seg_geom(n_items);
+    const int tid = threadIdx.x;
+    const uint32_t v = tid < g.G ? ws->seg_ties[tid] : 0u;
+    uint32_t total;
+    const uint32_t excl = block_excl_scan(v, s_part, &total);
+    int64_t local_need = need - st->tie_base;                // ties of lower ranks come first
+    if (local_need <= 0) return;
+    if (local_need >= (int64_t)total) { t.rs = t.re = n_items; return; }
+    if (v && (int64_t)excl <= local_need && local_need < (int64_t)excl + v) { s_res[0] = (uint32_t)tid; s_res[1] = (uint32_t)(local_need - excl); }
+    __syncthreads();
+    const int B = (int)s_res[0];
+    const uint32_t within = s_res[1];
+    const int64_t b0 = (int64_t)B * g.L, b1 = b0 + g.L < n_items ? b0 + g.L : n_items;
+    if (within == 0) { t.rs = t.re = b0; return; }
+    if (!(st->flags & 1u)) { t.rs = b0; t.re = b1; t.need_in = within; return; }   // no piece counts: rank the whole segment
+    const PieceGeom pg = piece_geom(b1 - b0);
+    uint32_t pc[16], mine = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int p0 = tid * 16 + q * 4;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (p0 < pg.n) x = *reinterpret_cast<const uint4*>(&ws->piece_counts[p0]);     // (entries >= pg.n inside a quad: masked below)
+        pc[q * 4] = p0 < pg.n ? x.x : 0u; pc[q * 4 + 1] = p0 + 1 < pg.n ? x.y : 0u;
+        pc[q * 4 + 2] = p0 + 2 < pg.n ? x.z : 0u; pc[q * 4 + 3] = p0 + 3 < pg.n ? x.w : 0u;
+        mine += pc[q * 4] + pc[q * 4 + 1] + pc[q * 4 + 2] + pc[q * 4 + 3];
+    }
+    uint32_t ptotal;
+    uint32_t pex = block_excl_scan(mine, s_part, &ptotal);
+    if (mine && pex <= within && within < pex + mine) {       // the first piece whose inclusive count exceeds `within`
+        int P = tid * 16;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (within >= pex + pc[j]) { pex += pc[j]; P = tid * 16 + j + 1; }
+            else break;
+        }
+        s_res[2] = (uint32_t)P; s_res[3] = within - pex;
+    }
+    if (tid == 0 && within >= ptotal) { s_res[2] = (uint32_t)pg.n; s_res[3] = 0; }      // (stale counts: cannot happen; keeps the read defined)
+    __syncthreads();
+    const int64_t P = (int64_t)s_res[2];
+    const uint32_t pin = s_res[3];
+    int64_t p0 = b0 + P * pg.tiles_per * 64, p1 = p0 + pg.tiles_per * 64;
+    if (p0 > b1) p0 = b1;
+    if (p1 > b1) p1 = b1;
+    if (pin == 0) { t.rs = t.re = p0; return; }
+    t.rs = p0; t.re = p1; t.need_in = pin;
+}
+
+// prune bits of one lane item (bit j = element j goes); `item` is the lane's item, lanes of a wave hold one 64-item tile
+template <int DT, bool FAST>
+__device__ __forceinline__ uint32_t thr_prune_bits(const uint32_t* raw, bool valid, int64_t item, const ThrCtx& t)
+{
+    constexpr int VEC = Traits<DT>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int64_t tile0 = uniform64(item - lane);
+    uint32_t ltm = 0, eqm = 0;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+        const uint32_t key = mag_key<DT>(raw[j]);
+        ltm |= (uint32_t)(key < t.tau) << j;
+        eqm |= (uint32_t)(key == t.tau) << j;
+    }
+    if (!valid) eqm = 0;
+    if (!t.on) return 0;
+    if (tile0 >= t.re) return ltm;                          // behind the region: ties stay
+    if (tile0 < t.rs) return ltm | eqm;                     // in front of it: ties go
+    // inside: ties in the region before this tile (re-read; the region is one tile unless the tensor is huge or the
+    // resolve launch had to give up on piece counts), then a wave scan of this tile's own
+    uint32_t before = 0;
+    for (int64_t it = t.rs + lane; it < tile0; it += 64) {
+        uint32_t r[VEC];
+        sweep_load<DT, FAST>(t.in, it, (t.numel + VEC - 1) / VEC, t.numel, r);
+        before += count_eq<DT>(r, t.tau);
+    }
+    before = wave_sum(before);
+    uint32_t prune = ltm;
+    const uint32_t cnt = __popc(eqm);
+    const uint32_t incl = wave_incl_scan(cnt);
+    uint32_t r = before + incl - cnt;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+        if ((eqm >> j) & 1u) { if (r < t.need_in) prune |= 1u << j; r++; }
+    }
+    return prune;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Unstructured: radix select on magnitude keys (15 bits in one pass for 16-bit dtypes; 11 + 11 + 9 for fp32).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ inline void select_digit(int dtype, int pass, int* shift, int* nbits)
+{
+    if (dtype == BFPQ_F32) {
+        if (pass == 0) { *shift = 20; *nbits = 11; }
+        else if (pass == 1) { *shift = 9; *nbits = 11; }
+        else { *shift = 0; *nbits = 9; }
+    } else { *shift = 0; *nbits = 15; }
+}
+
+template <int DT> __device__ __forceinline__ void load_raw_vec(const void* in, int64_t item, uint32_t* raw)
+{
+    constexpr int VEC = Traits<DT>::VEC;
+    const uint4 v = reinterpret_cast<const uint4*>(in)[item];
+    if constexpr (VEC == 4) { raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w; }
+    else {
+        raw[0] = v.x & 0xffffu; raw[1] = v.x >> 16; raw[2] = v.y & 0xffffu; raw[3] = v.y >> 16;
+        raw[4] = v.z & 0xffffu; raw[5] = v.z >> 16; raw[6] = v.w & 0xffffu; raw[7] = v.w >> 16;
+    }
+}
+
+// one lane item of a sweep.  FAST: pointer 16-B aligned and numel a multiple of the vector width -> unconditional vector
+// loads (index clamped), so a prefetch stays in flight; otherwise element loads with bounds checks.
+template <int DT, bool FAST>
+__device__ __forceinline__ void sweep_load(const void* in, int64_t item, int64_t n_items, int64_t numel, uint32_t* raw)
+{
+    using raw_t = typename Traits<DT>::raw_t;
+    constexpr int VEC = Traits<DT>::VEC;
+    if constexpr (FAST) load_raw_vec<DT>(in, item < n_items ? item : n_items - 1, raw);
+    else {
+        const int64_t e0 = item * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; j++)                          // past-the-end elements: a key that is never < or == tau
+            raw[j] = (e0 + j < numel) ? (uint32_t)reinterpret_cast<const raw_t*>(in)[e0 + j] : (Traits<DT>::INF + 2u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host helpers
+// ---------------------------------------------------------------------------------------------
+inline float h_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+inline uint32_t h_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+inline float h_round_bf16(float f)
+{
+    uint32_t u = h_f2u(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return f;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return h_u2f(u & 0xffff0000u);
+}
+
+// fp32 -> nearest fp16 (ties to even) -> fp32, via exact double arithmetic on the fp16 grid
+inline float h_round_f16(float f)
+{
+    if (f != f || f == 0.0f) return f;
+    const double a = fabs((double)f);
+    if (a >= 65520.0) return f < 0 ? -INFINITY : INFINITY;
+    int ex;
+    frexp(a, &ex);                               // a = m * 2^ex, m in [0.5, 1)
+    int q = ex - 11;                             // 11 significant bits
+    if (q < -24) q = -24;                        // subnormal grid
+    const double r = nearbyint(ldexp(a, -q));    // default rounding mode: ties to even
+    const double v = ldexp(r, q);
+    return (float)(f < 0 ? -v : v);
+}
+
+inline float h_round(float f, int dtype) { return dtype == BFPQ_F32 ? f : (dtype == BFPQ_F16 ? h_round_f16(f) : h_round_bf16(f)); }
+
+inline int dtype_vec(int dtype) { return dtype == BFPQ_F32 ? 4 : 8; }
+inline int dtype_size(int dtype) { return dtype == BFPQ_F32 ? 4 : 2; }
+inline bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// workgroups for `work_threads` grid-stride work items: at most kMaxGrid, and balanced -- every
+// workgroup gets the same number of sweeps (22016 blocks of work -> 18 sweeps x 1224 workgroups, not
+// 1280 workgroups of which 256 do one sweep more)
+inline int grid_for(int64_t work_threads)
+{
+    int64_t g = (work_threads + kThreads - 1) / kThreads;
+    if (g < 1) g = 1;
+    if (g <= kMaxGrid) return (int)g;
+    const int64_t sweeps = (g + kMaxGrid - 1) / kMaxGrid;
+    return (int)((g + sweeps - 1) / sweeps);
+}
+
+}  // namespace bfpq_dev

@@ -26,212 +26,13 @@ using namespace bfpq;
 
 extern "C" __attribute__((visibility("hidden"))) int bfpq_g_gemm_rt;   // bfpq_gemm.hip
 
+#include "bfpq_device.h"
+
+extern "C" { __attribute__((visibility("hidden"))) int bfpq_g_max_grid = BFPQ_MAXGRID; }
+
+using namespace bfpq_dev;
+
 namespace {
-
-#ifndef BFPQ_MAXGRID
-#define BFPQ_MAXGRID 1024          // 256 CUs x 4 workgroups, grid-stride beyond that (A/B over 5 shapes: 1024 best or tied)
-#endif
-#ifndef BFPQ_NT
-#define BFPQ_NT 1                  // non-temporal loads/stores on the once-touched streams (A/B: +6..8 %)
-#endif
-constexpr int kThreads = 256;
-int g_max_grid = BFPQ_MAXGRID;           // tuning knob (bfpq_tune), process-wide
-#define kMaxGrid g_max_grid
-
-__device__ __forceinline__ uint4 stream_load(const uint4* p)
-{
-#if BFPQ_NT
-    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-    const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
-}
-__device__ __forceinline__ void stream_store(uint4* p, uint4 v)
-{
-#if BFPQ_NT
-    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-    const u4v w = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(w, reinterpret_cast<u4v*>(p));
-#else
-    *p = v;
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------
-// small device helpers
-// ---------------------------------------------------------------------------------------------
-typedef short short2v __attribute__((ext_vector_type(2)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t cmp3(uint32_t a, uint32_t b) { return (uint32_t)(a > b) + (uint32_t)(a >= b); }
-
-// signature index of one group of 4 magnitude keys (see bfpq_nm4_lut_host): sum_p c_p 3^p, c in {0,1,2}
-__device__ __forceinline__ uint32_t nm4_index(uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3)
-{
-    // keys < 2^31: the signed difference clamped to [-1,1] is the 3-way comparison
-    auto c = [](uint32_t a, uint32_t b) { const int d = (int)a - (int)b; return d < -1 ? -1 : (d > 1 ? 1 : d); };
-    return (uint32_t)(364 + c(k0, k1) + 3 * c(k0, k2) + 9 * c(k0, k3) + 27 * c(k1, k2) + 81 * c(k1, k3) + 243 * c(k2, k3));
-}
-
-// keep-mask of one group of 2 (keep 1): stable insertion sort of two -> index 0 goes on a tie
-__device__ __forceinline__ uint32_t nm2_keep(uint32_t k0, uint32_t k1, int N)
-{
-    if (N >= 2) return 3u;
-    return (k1 < k0) ? 1u : 2u;
-}
-
-// packed 16-bit VALU ops, spelled out: hipcc scalarises a clamp written with vector builtins into
-// per-half v_cmp / v_cndmask chains (seen in the ISA of the first version of this kernel)
-__device__ __forceinline__ uint32_t pk_sub_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_sub_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_max_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ uint32_t pk_mad_i16(uint32_t a, uint32_t b, uint32_t c) { uint32_t d; asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-__device__ __forceinline__ uint32_t pk_add_i16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_add_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-// same with the constant operand in an SGPR (one scalar operand per VALU instruction is allowed)
-__device__ __forceinline__ uint32_t pk_ashr_i16_s(uint32_t a, uint32_t sh) { uint32_t d; asm("v_pk_ashrrev_i16 %0, %1, %2" : "=v"(d) : "s"(sh), "v"(a)); return d; }
-__device__ __forceinline__ uint32_t pk_max_i16_s(uint32_t a, uint32_t k) { uint32_t d; asm("v_pk_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k)); return d; }
-__device__ __forceinline__ uint32_t pk_min_i16_s(uint32_t a, uint32_t k) { uint32_t d; asm("v_pk_min_i16 %0, %1, %2" : "=v"(d) : "v"(a), "s"(k)); return d; }
-__device__ __forceinline__ uint32_t pk_mad_i16_s(uint32_t a, uint32_t k, uint32_t c) { uint32_t d; asm("v_pk_mad_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c)); return d; }
-
-// max over the 2^n adjacent lanes that share one block, by DPP where the ISA has a pattern for it
-template <int CTRL> __device__ __forceinline__ uint32_t dpp_max(uint32_t v)
-{
-    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
-    return o > v ? o : v;
-}
-__device__ __forceinline__ uint32_t shfl_max(uint32_t v, int o)
-{
-    const uint32_t other = (uint32_t)__shfl_xor((int)v, o, 64);
-    return other > v ? other : v;
-}
-// LPBT > 0: lanes per block known at compile time; LPBT < 0: runtime value lpb
-template <int LPBT> __device__ __forceinline__ uint32_t group_max(uint32_t v, int lpb)
-{
-    const int n = LPBT > 0 ? LPBT : lpb;
-    if (n >= 2) v = dpp_max<0xB1>(v);        // quad_perm [1,0,3,2]
-    if (n >= 4) v = dpp_max<0x4E>(v);        // quad_perm [2,3,0,1]
-    if (n >= 8) v = dpp_max<0x141>(v);       // row_half_mirror: the other quad of the 8-lane half
-    if (n >= 16) v = dpp_max<0x140>(v);      // row_mirror: the other half of the 16-lane row
-    if (n >= 32) v = shfl_max(v, 16);
-    if (n >= 64) v = shfl_max(v, 32);
-    return v;
-}
-
-struct FusedArgs {
-    const void* in;
-    void* out_deq;
-    void* out_codes;
-    int8_t* out_exp;
-    int64_t n_items;          // numel / VEC
-    const uint8_t* exp_win;   // global, BFPQ_EXP_WIN_ENTRIES
-    const uint8_t* nm_lut;    // global, BFPQ_NM4_LUT_ENTRIES (NM == 4)
-    uint64_t seed;
-    float eps_dt;
-    int lpb;                  // lanes per block (power of two <= 64); 0 = no quantization
-    int mant_bits;
-    int N;
-    int code_bits;
-    int force_slow;           // mant_bits wider than the dtype significand: always emulate step by step
-    const bfpq_select_state* sel;   // NM == -1 (global magnitude threshold): select result,
-    const uint32_t* tie_counts;     //   ties per wave-chunk (k_tie_count),
-    const int64_t* tie_base;        //   ties held by lower ranks (nullable)
-    unsigned long long* unit_status;  // NM == -1, one-pass mode: flag + tie count per unit of kThreads x 8 items (zeroed); else null
-    int* unit_error;                  //   set to 1 if a look-back spin ran into its cap (never in a healthy run)
-};
-
-// wave-level inclusive scan (lane order)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
-{
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)v, o, 64);
-        if (lane >= o) v += up;
-    }
-    return v;
-}
-__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += (unsigned long long)__shfl_xor((long long)v, o, 64);
-    return v;
-}
-
-// Tie ranks without block barriers and without a fixed traversal order: the tensor is cut into "wave
-// tiles" of 64 lane items (64 x 16 B, exactly what one wavefront handles per step).  k_tie_count writes
-// the number of threshold ties of every tile, k_tie_chunk_sum / k_tie_scan turn that array into exclusive prefixes (one
-// workgroup; the array is L2-sized), and a consumer wave reads prefix[tile] -- unconditionally, once per
-// tile, so that no load sits inside a branch of the streaming loop -- and adds a wave scan of its own
-// lanes' tie counts when the tile holds a tie at all.
-__host__ __device__ inline int64_t tie_tiles(int64_t n_items) { return (n_items + 63) / 64; }
-// workspace layout (uint32): [0, cpad) exclusive prefix over chunks of 64 tiles; [cpad, cpad + 64*chunks) ties per tile
-struct TieLayout { int64_t n_tiles, n_chunks, cpad; };
-__host__ __device__ inline TieLayout tie_layout(int64_t n_items)
-{
-    TieLayout l;
-    l.n_tiles = tie_tiles(n_items);
-    l.n_chunks = (l.n_tiles + 63) / 64;
-    l.cpad = (l.n_chunks + 63) / 64 * 64;
-    if (l.cpad < 64) l.cpad = 64;
-    return l;
-}
-
-// threshold state as wave-uniform scalars
-struct ThrCtx {
-    uint32_t tau; unsigned long long need, base; bool on, ranked, allties;
-    const uint32_t* coarse; const uint32_t* counts;
-    __device__ __forceinline__ void load(const bfpq_select_state* st, const uint32_t* tie_ws, const int64_t* tie_base, int64_t n_items)
-    {
-        tau = st->tau; need = (unsigned long long)st->need;
-        on = st->k > 0; ranked = on && st->need != 0 && st->need != st->ties; allties = st->need == st->ties;
-        coarse = tie_ws; counts = tie_ws + tie_layout(n_items).cpad;
-        base = tie_base ? (unsigned long long)*tie_base : 0ull;
-    }
-};
-
-// The two unconditional loads a consumer wave makes per tile (nothing is loaded inside a branch of the
-// streaming loop): ties before the tile's chunk of 64 tiles, and this lane's entry of the chunk's counts.
-struct TileTies { uint32_t chunk_prefix, tile_prefix; };
-__device__ __forceinline__ TileTies tile_ties(int64_t item, const ThrCtx& t)
-{
-    const int64_t tile = item >> 6;                        // wave-uniform: both loads are broadcasts
-    TileTies r;
-    r.chunk_prefix = t.coarse[tile >> 6];
-    r.tile_prefix = t.counts[tile];
-    return r;
-}
-
-// prune bits of one lane item (bit j = element j goes)
-template <int DT>
-__device__ __forceinline__ uint32_t thr_prune_bits(const uint32_t* raw, bool valid, int64_t item, const TileTies tt, const ThrCtx& t)
-{
-    constexpr int VEC = Traits<DT>::VEC;
-    uint32_t ltm = 0, eqm = 0;
-#pragma unroll
-    for (int j = 0; j < VEC; j++) {
-        const uint32_t key = mag_key<DT>(raw[j]);
-        ltm |= (uint32_t)(key < t.tau) << j;
-        eqm |= (uint32_t)(key == t.tau) << j;
-    }
-    if (!valid) eqm = 0;
-    if (!t.on) return 0;
-    uint32_t prune = ltm;
-    if (t.ranked) {
-        if (__ballot(eqm != 0)) {                          // most wave tiles hold no element equal to tau
-            const uint32_t cnt = __popc(eqm);
-            const uint32_t incl = wave_incl_scan(cnt);
-            unsigned long long r = t.base + tt.chunk_prefix + tt.tile_prefix + (incl - cnt);
-#pragma unroll
-            for (int j = 0; j < VEC; j++) {
-                if ((eqm >> j) & 1u) { if (r < t.need) prune |= 1u << j; r++; }
-            }
-        }
-    } else if (t.allties) prune |= eqm;
-    return prune;
-}
 
 // scale of a block on the branch-free path; ok == false -> the caller emulates step by step instead
 struct FastScale { float inv, interval, qmax; int e; bool ok; };
@@ -290,25 +91,40 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
 
     // N:M mask on the 4 dwords of an item (16-bit dtypes: 2 groups of 4; fp32: 1 group)
     ThrCtx thr;
-    bool unit_mode = false;
     bool item_valid = true;
     int64_t item_index = 0;
-    if constexpr (NM == -1) thr.load(a.sel, a.tie_counts, a.tie_base, a.n_items);
     auto nm_mask = [&](uint32_t& d0, uint32_t& d1, uint32_t& d2, uint32_t& d3) __attribute__((always_inline)) {
         if constexpr (NM == -1) {                       // global magnitude threshold (unstructured, bfp_ops.py:61-71)
-            uint32_t raw[VEC];
-            if constexpr (VEC == 4) { raw[0] = d0; raw[1] = d1; raw[2] = d2; raw[3] = d3; }
-            else {
-                raw[0] = d0 & 0xffffu; raw[1] = d0 >> 16; raw[2] = d1 & 0xffffu; raw[3] = d1 >> 16;
-                raw[4] = d2 & 0xffffu; raw[5] = d2 >> 16; raw[6] = d3 & 0xffffu; raw[7] = d3 >> 16;
-            }
-            const TileTies tt = unit_mode ? TileTies{0u, 0u} : tile_ties(item_index, thr);   // unit mode: thr.base carries the rank
-            const uint32_t prune = thr_prune_bits<DT>(raw, item_valid, item_index, tt, thr);
-            if constexpr (VEC == 4) {
-                d0 = (prune & 1u) ? 0u : d0; d1 = (prune & 2u) ? 0u : d1; d2 = (prune & 4u) ? 0u : d2; d3 = (prune & 8u) ? 0u : d3;
+            const int64_t tile0 = uniform64(item_index - (threadIdx.x & 63));      // the wave's 64 lanes hold one aligned tile
+            const bool ranked = tile0 >= thr.rs && tile0 < thr.re;
+            if (__builtin_expect(!ranked, 1)) {
+                // every tile but (normally) one: the ties of this tile all go (in front of the cut) or all stay, i.e. one
+                // comparison against tau + 1 or tau
+                const uint32_t teff = thr.tau + (tile0 < thr.rs ? 1u : 0u);     // (tau == 0 when nothing is pruned at all)
+                if constexpr (VEC == 8) {
+                    // packed: keys <= 0x7f81 and teff <= 0x7f82, so teff - 1 - key fits 16 signed bits; its sign says keep
+                    const uint32_t absm = T::ABS | (T::ABS << 16), nanc = (T::INF + 1u) | ((T::INF + 1u) << 16);
+                    const uint32_t tm1 = (teff - 1u) & 0xffffu, t2 = tm1 | (tm1 << 16);
+                    auto keep = [&](uint32_t d) { return pk_ashr_i16_s(pk_sub_i16(t2, pk_min_i16_s(d & absm, nanc)), 0x000f000fu); };
+                    d0 &= keep(d0); d1 &= keep(d1); d2 &= keep(d2); d3 &= keep(d3);
+                } else {
+                    d0 = mag_key<DT>(d0) < teff ? 0u : d0; d1 = mag_key<DT>(d1) < teff ? 0u : d1;
+                    d2 = mag_key<DT>(d2) < teff ? 0u : d2; d3 = mag_key<DT>(d3) < teff ? 0u : d3;
+                }
             } else {
-                auto m = [](uint32_t pr) { return ((pr & 1u) ? 0u : 0xffffu) | ((pr & 2u) ? 0u : 0xffff0000u); };
-                d0 &= m(prune); d1 &= m(prune >> 2); d2 &= m(prune >> 4); d3 &= m(prune >> 6);
+                uint32_t raw[VEC];
+                if constexpr (VEC == 4) { raw[0] = d0; raw[1] = d1; raw[2] = d2; raw[3] = d3; }
+                else {
+                    raw[0] = d0 & 0xffffu; raw[1] = d0 >> 16; raw[2] = d1 & 0xffffu; raw[3] = d1 >> 16;
+                    raw[4] = d2 & 0xffffu; raw[5] = d2 >> 16; raw[6] = d3 & 0xffffu; raw[7] = d3 >> 16;
+                }
+                const uint32_t prune = thr_prune_bits<DT, true>(raw, item_valid, item_index, thr);
+                if constexpr (VEC == 4) {
+                    d0 = (prune & 1u) ? 0u : d0; d1 = (prune & 2u) ? 0u : d1; d2 = (prune & 4u) ? 0u : d2; d3 = (prune & 8u) ? 0u : d3;
+                } else {
+                    auto m = [](uint32_t pr) { return ((pr & 1u) ? 0u : 0xffffu) | ((pr & 2u) ? 0u : 0xffff0000u); };
+                    d0 &= m(prune); d1 &= m(prune >> 2); d2 &= m(prune >> 4); d3 &= m(prune >> 6);
+                }
             }
         } else if constexpr (NM == 8 && VEC == 4) {
             // fp32: a group of 8 is two adjacent lane items (even lane: elements 0-3, odd lane: 4-7; item parity = lane
@@ -648,115 +464,9 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
     }
     __syncthreads();
     if constexpr (NM == -1) {
-        if (a.unit_status != nullptr && thr.ranked) {
-            // ONE-PASS unstructured apply.  A workgroup takes units of kThreads x IPT consecutive lane items (32 KiB of
-            // bf16), keeps a unit in registers, counts its threshold ties per wave tile, publishes the unit's count in a
-            // packed (flag, value) word and obtains the number of ties in all earlier units by decoupled look-back over
-            // the lower-numbered units (device-scope atomics on those words only -- no __threadfence(), which is an L2
-            // write-back on this part); then prunes with exact flat-order ranks, quantizes and stores from the registers.
-            // The tensor is read once instead of twice (no k_tie_count pass) and three launches disappear.
-            // Progress: the launcher bounds the grid by the resident capacity, so every unit waited for belongs to a
-            // workgroup that is running; spins are capped all the same (a.unit_error).
-            constexpr int IPT = 8, NW = kThreads / 64;
-            constexpr unsigned long long F_AGG = 1ull << 62, F_PRE = 2ull << 62, VMASK = (1ull << 62) - 1;
-            __shared__ uint32_t s_cnt[IPT * NW];                                // ties per wave tile, order (i, wave)
-            __shared__ uint4 s_items[IPT][kThreads];                            // the unit, parked per thread between count and apply
-                                                                                // (in registers the 8 inlined bodies cost 160 VGPRs)
-            __shared__ unsigned long long s_unit_base;
-            unit_mode = true;
-            const unsigned long long base0 = thr.base;
-            const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-            const int64_t unit_items = (int64_t)kThreads * IPT;
-            const int64_t n_units = (a.n_items + unit_items - 1) / unit_items;
-            u4v d[IPT];
-            {
-                const int64_t f0 = (int64_t)blockIdx.x * unit_items + threadIdx.x;
-#pragma unroll
-                for (int i = 0; i < IPT; i++) d[i] = fetch(f0 + (int64_t)i * kThreads);
-            }
-            for (int64_t u = blockIdx.x; u < n_units; u += gridDim.x) {
-                const int64_t first = u * unit_items + threadIdx.x;
-#pragma unroll
-                for (int i = 0; i < IPT; i++) {
-                    const uint32_t dw[4] = {d[i].x, d[i].y, d[i].z, d[i].w};
-                    uint32_t cnt = 0;
-#pragma unroll
-                    for (int j = 0; j < VEC; j++) {
-                        const uint32_t r = VEC == 4 ? dw[j] : ((dw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
-                        cnt += mag_key<DT>(r) == thr.tau;
-                    }
-                    if (first + (int64_t)i * kThreads >= a.n_items) cnt = 0;
-                    for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, 64);
-                    if (lane == 0) s_cnt[i * NW + w] = cnt;
-                    s_items[i][threadIdx.x] = u4(d[i]);
-                }
-                __syncthreads();
-                {                                                   // the next unit's loads fly during the look-back and the apply
-                    const int64_t fn = (u + gridDim.x) * unit_items + threadIdx.x;      // (clamped by fetch past the end)
-#pragma unroll
-                    for (int i = 0; i < IPT; i++) d[i] = fetch(fn + (int64_t)i * kThreads);
-                }
-                if (w == 0) {
-                    const uint32_t v = lane < IPT * NW ? s_cnt[lane] : 0u;
-                    const uint32_t incl = wave_incl_scan(v);
-                    const unsigned long long total = (unsigned long long)(uint32_t)__shfl((int)incl, IPT * NW - 1, 64);
-                    if (lane == 0)
-                        __hip_atomic_store(&a.unit_status[u], (u == 0 ? F_PRE : F_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    unsigned long long excl = 0;
-                    if (u > 0) {
-                        // One poll reads LB x 64 status words.  Wider polls were tried (LB = 4, 16: the whole grid at once) and
-                        // measured SLOWER (cfg 4: 61.9 us with 1, 64.2 with 4, 68.3 with 16): the uncached device-scope loads
-                        // cost more than the look-back steps they save.
-                        constexpr int LB = 1;
-                        int64_t look = u - 1;
-                        int spins = 0;
-                        bool done = false;
-                        while (!done) {
-                            unsigned long long st[LB];
-#pragma unroll
-                            for (int j = 0; j < LB; j++) {
-                                const int64_t idx = look - (int64_t)j * 64 - lane;
-                                st[j] = idx >= 0 ? __hip_atomic_load(&a.unit_status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                                 : F_PRE;                               // in front of unit 0: prefix 0
-                            }
-                            unsigned long long part = 0;
-                            bool wait = false;
-#pragma unroll
-                            for (int j = 0; j < LB; j++) {
-                                if (done || wait) continue;                             // (wave-uniform flags)
-                                const uint32_t flag = (uint32_t)(st[j] >> 62);
-                                const unsigned long long m_pre = __ballot(flag == 2u), m_empty = __ballot(flag == 0u);
-                                const int fp = m_pre ? __ffsll((long long)m_pre) - 1 : 64;  // nearest predecessor with a prefix
-                                const unsigned long long nearer = fp >= 64 ? ~0ull : ((1ull << fp) - 1ull);
-                                if (m_empty & nearer) { wait = true; continue; }        // a nearer unit has not published yet
-                                part += wave_sum64(lane <= fp ? (st[j] & VMASK) : 0ull);
-                                if (fp < 64) done = true;
-                            }
-                            if (wait) {                                                 // poll the same window again
-                                if (++spins > (1 << 20)) { if (lane == 0 && a.unit_error) *a.unit_error = 1; break; }
-                                __builtin_amdgcn_s_sleep(1);
-                                continue;
-                            }
-                            excl += part;
-                            look -= (int64_t)LB * 64;
-                        }
-                        if (lane == 0)
-                            __hip_atomic_store(&a.unit_status[u], F_PRE | ((excl + total) & VMASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (lane < IPT * NW) s_cnt[lane] = incl - v;                        // ties of the unit's earlier wave tiles
-                    if (lane == 0) s_unit_base = excl;
-                }
-                __syncthreads();
-                const unsigned long long ubase = base0 + s_unit_base;
-#pragma unroll 1
-                for (int i = 0; i < IPT; i++) {
-                    thr.base = ubase + s_cnt[i * NW + w];
-                    body(std::true_type{}, first + (int64_t)i * kThreads, s_items[i][threadIdx.x]);
-                }
-                __syncthreads();                                                        // s_cnt is rewritten by the next unit
-            }
-            return;
-        }
+        __shared__ uint32_t s_part[16];
+        __shared__ uint32_t s_res[8];
+        thr_setup<DT>(thr, a.selws, a.in, a.n_items * VEC, a.n_items, s_part, s_res);
     }
     // One more memory op behind the first load, result unused.  At the loop top the back edge arrives with [load, store]
     // outstanding and the entry edge with [load] only; one s_waitcnt immediate must serve both edges, so the compiler
@@ -1085,368 +795,6 @@ __global__ void __launch_bounds__(kThreads) k_quant_rows_vec(const void* in, voi
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Unstructured: radix select on magnitude keys.
-// ---------------------------------------------------------------------------------------------
-__host__ __device__ inline void select_digit(int dtype, int pass, int* shift, int* nbits)
-{
-    if (dtype == BFPQ_F32) {
-        if (pass == 0) { *shift = 20; *nbits = 11; }
-        else if (pass == 1) { *shift = 9; *nbits = 11; }
-        else { *shift = 0; *nbits = 9; }
-    } else { *shift = 0; *nbits = 15; }
-}
-
-template <int DT>
-__global__ void __launch_bounds__(1024) k_select_hist(const void* in, int64_t numel, int shift, int nbits, int first,
-                                                      const bfpq_select_state* st, uint32_t* hist,
-                                                      unsigned long long* zero_ptr, int64_t zero_n)
-{
-    // (the one-pass apply that follows needs its unit status words zeroed: done here, for free, instead of a memset node)
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < zero_n; i += (int64_t)gridDim.x * blockDim.x) zero_ptr[i] = 0ull;
-    using T = Traits<DT>;
-    using raw_t = typename T::raw_t;
-    constexpr int VEC = T::VEC;
-    extern __shared__ uint32_t s_hist[];
-    const int nbins = 1 << nbits;
-    for (int i = threadIdx.x; i < nbins; i += blockDim.x) s_hist[i] = 0;
-    __syncthreads();
-    const uint32_t pmask = first ? 0u : st->prefix_mask, pval = first ? 0u : st->prefix;   // pass 0 reads no state
-    const uint32_t dmask = (uint32_t)nbins - 1u;
-    const raw_t* src = reinterpret_cast<const raw_t*>(in);
-    const bool aligned = (reinterpret_cast<uintptr_t>(in) & 15u) == 0;
-    const int64_t n_items = aligned ? numel / VEC : 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    if (n_items > 0) {
-        // one-ahead prefetch with clamped, unconditional loads (a lone load per wave is latency-bound)
-        const int64_t last = n_items - 1;
-        int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-        uint4 v = reinterpret_cast<const uint4*>(in)[item < last ? item : last];
-        for (; item < n_items; item += stride) {
-            const int64_t pf = item + stride;
-            const uint4 nv = reinterpret_cast<const uint4*>(in)[pf < last ? pf : last];
-            if constexpr (VEC == 8) {
-                // 16-bit dtypes: one pass over the whole 15-bit key (shift 0, no prefix to match): two keys per packed
-                // and/min, unconditional LDS atomics
-                const uint32_t absm = T::ABS | (T::ABS << 16), nanc = (T::INF + 1u) | ((T::INF + 1u) << 16);
-                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t k2 = pk_min_i16_s(d[j] & absm, nanc);
-                    atomicAdd(&s_hist[k2 & 0xffffu], 1u);
-                    atomicAdd(&s_hist[k2 >> 16], 1u);
-                }
-            } else {
-                const uint32_t raw[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t key = mag_key<DT>(raw[j]);
-                    if ((key & pmask) == pval) atomicAdd(&s_hist[(key >> shift) & dmask], 1u);
-                }
-            }
-            v = nv;
-        }
-    }
-    for (int64_t i = n_items * VEC + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += stride) {
-        const uint32_t key = mag_key<DT>((uint32_t)src[i]);
-        if ((key & pmask) == pval) atomicAdd(&s_hist[(key >> shift) & dmask], 1u);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nbins; i += blockDim.x) {
-        const uint32_t c = s_hist[i];
-        if (c) atomicAdd(&hist[i], c);
-    }
-}
-
-// One block of 1024 threads (16 waves): first bin whose inclusive prefix count reaches k_rem.
-// Wave w owns a contiguous segment of nbins/16 bins, lane l the PER = seg/64 contiguous bins
-// [l*PER, (l+1)*PER) of it -- all of a lane's loads are issued together (one memory latency), the
-// rest is register arithmetic plus one wave scan in the wave that holds the crossing.
-// Leaves the histogram zeroed for the next pass / call.
-template <int PER>
-__global__ void __launch_bounds__(1024) k_select_scan(bfpq_select_state* st, uint32_t* hist, int shift, int nbits, int last, int first, int64_t k_first)
-{
-    __shared__ unsigned long long s_tot[16];
-    const int nbins = 1 << nbits;
-    const int seg = nbins / 16;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool active = lane * PER < seg;                 // seg < 64 (512-bin digit): upper lanes idle
-    uint32_t v[PER];
-    if constexpr (PER == 32) {
-        // A lane owns 32 contiguous bins (128 B); loading them directly makes every load instruction touch 64 different
-        // 128-byte lines and the 8 loads of a wave touch the same 64 lines again -- with 16 waves that is 4x the L1, so
-        // the lines come from L2 up to 8 times (measured 8.8 us for 128 KiB).  Instead the wave reads its 8 KiB segment
-        // with coalesced 16-byte loads and transposes it through LDS (row stride 36 dwords: 16-byte aligned rows).
-        extern __shared__ uint32_t s_seg[];                     // [16 waves][64 lanes][36]
-        uint32_t* mine_seg = s_seg + w * (64 * 36);
-        const uint4* src4 = reinterpret_cast<const uint4*>(hist + w * seg);
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int b4 = j * 64 + lane;                          // 16-byte item inside the segment: bins 4 b4 .. 4 b4 + 3
-            const uint4 q = src4[b4];
-            *reinterpret_cast<uint4*>(mine_seg + (b4 >> 3) * 36 + (b4 & 7) * 4) = q;   // owner lane b4 / 8, offset (b4 % 8) * 4
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int j = 0; j < 32; j += 4) {
-            const uint4 q = *reinterpret_cast<const uint4*>(mine_seg + lane * 36 + j);
-            v[j] = q.x; v[j + 1] = q.y; v[j + 2] = q.z; v[j + 3] = q.w;
-        }
-    } else if constexpr (PER % 4 == 0) {
-#pragma unroll
-        for (int j = 0; j < PER; j += 4) {
-            const uint4 q = *reinterpret_cast<const uint4*>(hist + w * seg + lane * PER + j);
-            v[j] = q.x; v[j + 1] = q.y; v[j + 2] = q.z; v[j + 3] = q.w;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < PER; j++) v[j] = active ? hist[w * seg + lane * PER + j] : 0u;
-    }
-    uint32_t mine = 0;
-#pragma unroll
-    for (int j = 0; j < PER; j++) mine += v[j];
-    const unsigned long long wtot = wave_sum64(mine);
-    if (lane == 0) s_tot[w] = wtot;
-    __syncthreads();
-    // the first pass starts the selection: k comes as an argument, the state is (re)initialised below
-    const unsigned long long k_rem = first ? (unsigned long long)k_first : (unsigned long long)st->k_rem;
-    unsigned long long before = 0;
-    int W = 15;                                          // k_rem beyond the total cannot happen (k <= numel)
-    for (int i = 0; i < 16; i++) {
-        if (k_rem <= before + s_tot[i]) { W = i; break; }
-        if (i < 15) before += s_tot[i];
-    }
-    if (w == W) {
-        const uint32_t incl = wave_incl_scan(mine);       // counts fit 32 bits per wave segment? no: use 64-bit compare below
-        const unsigned long long lane_before = before + (unsigned long long)(incl - mine);
-        const unsigned long long m = __ballot(active && lane_before + mine >= k_rem);
-        int l = m ? __ffsll((long long)m) - 1 : 63;
-        if (k_rem == 0) l = 0;
-        if (lane == l) {
-            unsigned long long run = lane_before;
-            int bin = W * seg + lane * PER + PER - 1;
-            uint32_t tie = v[PER - 1];
-            bool found = false;
-#pragma unroll
-            for (int j = 0; j < PER; j++) {
-                if (!found) {
-                    if (k_rem <= run + v[j]) { bin = W * seg + lane * PER + j; tie = v[j]; found = true; }
-                    else run += v[j];
-                }
-            }
-            if (k_rem == 0) { bin = 0; run = 0; }
-            if (first) {
-                st->prefix = 0; st->prefix_mask = 0; st->tau = 0; st->done = 0; st->need = 0; st->ties = 0;
-                st->k = k_first; st->reserved[0] = 0; st->reserved[1] = 0;
-            }
-            st->prefix |= (uint32_t)bin << shift;
-            st->prefix_mask |= ((uint32_t)nbins - 1u) << shift;
-            st->k_rem = (int64_t)(k_rem - run);
-            if (last) {
-                st->tau = st->prefix;
-                st->need = st->k_rem;
-                st->ties = (int64_t)tie;
-                st->done = 1;
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nbins / 4; i += 1024) reinterpret_cast<uint4*>(hist)[i] = make_uint4(0, 0, 0, 0);   // nbins % 4 == 0
-}
-
-template <int DT> __device__ __forceinline__ void load_raw_vec(const void* in, int64_t item, uint32_t* raw)
-{
-    constexpr int VEC = Traits<DT>::VEC;
-    const uint4 v = reinterpret_cast<const uint4*>(in)[item];
-    if constexpr (VEC == 4) { raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w; }
-    else {
-        raw[0] = v.x & 0xffffu; raw[1] = v.x >> 16; raw[2] = v.y & 0xffffu; raw[3] = v.y >> 16;
-        raw[4] = v.z & 0xffffu; raw[5] = v.z >> 16; raw[6] = v.w & 0xffffu; raw[7] = v.w >> 16;
-    }
-}
-
-// item-based grid-stride sweep with a one-ahead prefetch.  FAST: pointer 16-B aligned and numel a
-// multiple of the vector width -> unconditional vector loads (index clamped), so the prefetch stays in
-// flight; otherwise element loads with bounds checks.
-template <int DT, bool FAST>
-__device__ __forceinline__ void sweep_load(const void* in, int64_t item, int64_t n_items, int64_t numel, uint32_t* raw)
-{
-    using raw_t = typename Traits<DT>::raw_t;
-    constexpr int VEC = Traits<DT>::VEC;
-    if constexpr (FAST) load_raw_vec<DT>(in, item < n_items ? item : n_items - 1, raw);
-    else {
-        const int64_t e0 = item * VEC;
-#pragma unroll
-        for (int j = 0; j < VEC; j++)                          // past-the-end elements: a key that is never < or == tau
-            raw[j] = (e0 + j < numel) ? (uint32_t)reinterpret_cast<const raw_t*>(in)[e0 + j] : (Traits<DT>::INF + 2u);
-    }
-}
-
-// ties per wave tile (+ their sum per chunk of 64 tiles, integer atomics: deterministic); skipped on the
-// device when ranks are not needed
-template <int DT, bool FAST>
-__global__ void __launch_bounds__(kThreads) k_tie_count(const void* in, int64_t numel, const bfpq_select_state* st, uint32_t* tie_ws)
-{
-    constexpr int VEC = Traits<DT>::VEC;
-    const int64_t n_items = (numel + VEC - 1) / VEC;
-    ThrCtx t; t.load(st, tie_ws, nullptr, n_items);
-    if (!t.ranked) return;
-    uint32_t* counts = tie_ws + tie_layout(n_items).cpad;
-    const int64_t n_round = (n_items + 63) / 64 * 64;
-    const int64_t stride = (int64_t)gridDim.x * kThreads;
-    int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    uint32_t cur[VEC], nxt[VEC];
-    sweep_load<DT, FAST>(in, item, n_items, numel, cur);
-    for (; item < n_round; item += stride) {                   // wave-uniform trip count
-        sweep_load<DT, FAST>(in, item + stride, n_items, numel, nxt);
-        uint32_t cnt = 0;
-#pragma unroll
-        for (int j = 0; j < VEC; j++) cnt += mag_key<DT>(cur[j]) == t.tau;
-        if (item >= n_items) cnt = 0;
-        for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, 64);
-        if ((threadIdx.x & 63) == 0) counts[item >> 6] = cnt;
-#pragma unroll
-        for (int j = 0; j < VEC; j++) cur[j] = nxt[j];
-    }
-}
-
-// sum of the 64 tile counts of every chunk: one wave per chunk, coalesced (no memory op inside a branch of
-// k_tie_count's streaming loop: a conditional atomic there tripled its run time)
-__global__ void __launch_bounds__(kThreads) k_tie_chunk_sum(const bfpq_select_state* st, uint32_t* tie_ws, int64_t n_tiles, int64_t n_chunks, int64_t cpad)
-{
-    const bool ranked = st->k > 0 && st->need != 0 && st->need != st->ties;
-    if (!ranked) return;
-    const int64_t c = ((int64_t)blockIdx.x * kThreads + threadIdx.x) >> 6;
-    if (c >= n_chunks) return;
-    const int lane = threadIdx.x & 63;
-    const int64_t tile = c * 64 + lane;
-    const uint32_t v = tile < n_tiles ? tie_ws[cpad + tile] : 0u;
-    uint32_t incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, o, 64);
-        if (lane >= o) incl += up;
-    }
-    // the tile's count is replaced by the ties of the chunk's earlier tiles: a consumer wave then needs two broadcast
-    // dwords per tile (chunk prefix + this) instead of the chunk's 64 counts and a masked wave sum
-    if (tile < n_tiles) tie_ws[cpad + tile] = incl - v;
-    if (lane == 63) tie_ws[c] = incl;
-}
-
-// exclusive prefix of the per-chunk sums, in place (one workgroup, n = tiles / 64 entries);
-// total -> st->reserved[0]
-__global__ void __launch_bounds__(1024) k_tie_scan(bfpq_select_state* st, uint32_t* coarse, int64_t n)
-{
-    __shared__ unsigned long long s_w[16];
-    const bool ranked = st->k > 0 && st->need != 0 && st->need != st->ties;
-    if (!ranked) { if (threadIdx.x == 0) st->reserved[0] = 0; return; }
-    const int64_t per = (n + 1023) / 1024;
-    const int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < n ? lo + per : n;
-    unsigned long long sum = 0;
-    for (int64_t i = lo; i < hi; i++) sum += coarse[i];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    unsigned long long incl = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned long long up = (unsigned long long)__shfl_up((long long)incl, o, 64);
-        if (lane >= o) incl += up;
-    }
-    if (lane == 63) s_w[w] = incl;
-    __syncthreads();
-    unsigned long long woff = 0, total = 0;
-    for (int i = 0; i < 16; i++) { if (i < w) woff += s_w[i]; total += s_w[i]; }
-    unsigned long long run = woff + incl - sum;
-    for (int64_t i = lo; i < hi; i++) { const uint32_t c = coarse[i]; coarse[i] = (uint32_t)run; run += c; }
-    if (threadIdx.x == 0) st->reserved[0] = (int64_t)total;
-}
-
-template <int DT, bool FAST>
-__global__ void __launch_bounds__(kThreads) k_threshold_apply(const void* in, void* out, int64_t numel,
-                                                              const bfpq_select_state* st, const uint32_t* tie_ws,
-                                                              const int64_t* tie_base)
-{
-    using raw_t = typename Traits<DT>::raw_t;
-    constexpr int VEC = Traits<DT>::VEC;
-    const int64_t n_items = (numel + VEC - 1) / VEC;
-    ThrCtx t; t.load(st, tie_ws, tie_base, n_items);
-    const int64_t n_round = (n_items + 63) / 64 * 64;
-    const int64_t stride = (int64_t)gridDim.x * kThreads;
-    int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    uint32_t cur[VEC], nxt[VEC];
-    sweep_load<DT, FAST>(in, item, n_items, numel, cur);
-    for (; item < n_round; item += stride) {
-        sweep_load<DT, FAST>(in, item + stride, n_items, numel, nxt);
-        const bool valid = item < n_items;
-        const TileTies tt = tile_ties(item, t);
-        const uint32_t prune = thr_prune_bits<DT>(cur, valid, item, tt, t);
-        if (valid) {
-            const int64_t e0 = item * VEC;
-            if constexpr (FAST) {
-                uint32_t r[VEC];
-#pragma unroll
-                for (int j = 0; j < VEC; j++) r[j] = ((prune >> j) & 1u) ? 0u : cur[j];
-                uint4 o;
-                if constexpr (VEC == 4) o = make_uint4(r[0], r[1], r[2], r[3]);
-                else o = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
-                reinterpret_cast<uint4*>(out)[item] = o;
-            } else {
-#pragma unroll
-                for (int j = 0; j < VEC; j++)
-                    if (e0 + j < numel) reinterpret_cast<raw_t*>(out)[e0 + j] = ((prune >> j) & 1u) ? (raw_t)0 : (raw_t)cur[j];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < VEC; j++) cur[j] = nxt[j];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// host helpers
-// ---------------------------------------------------------------------------------------------
-inline float h_u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
-inline uint32_t h_f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
-
-float h_round_bf16(float f)
-{
-    uint32_t u = h_f2u(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return f;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return h_u2f(u & 0xffff0000u);
-}
-
-// fp32 -> nearest fp16 (ties to even) -> fp32, via exact double arithmetic on the fp16 grid
-float h_round_f16(float f)
-{
-    if (f != f || f == 0.0f) return f;
-    const double a = fabs((double)f);
-    if (a >= 65520.0) return f < 0 ? -INFINITY : INFINITY;
-    int ex;
-    frexp(a, &ex);                               // a = m * 2^ex, m in [0.5, 1)
-    int q = ex - 11;                             // 11 significant bits
-    if (q < -24) q = -24;                        // subnormal grid
-    const double r = nearbyint(ldexp(a, -q));    // default rounding mode: ties to even
-    const double v = ldexp(r, q);
-    return (float)(f < 0 ? -v : v);
-}
-
-float h_round(float f, int dtype) { return dtype == BFPQ_F32 ? f : (dtype == BFPQ_F16 ? h_round_f16(f) : h_round_bf16(f)); }
-
-int dtype_vec(int dtype) { return dtype == BFPQ_F32 ? 4 : 8; }
-int dtype_size(int dtype) { return dtype == BFPQ_F32 ? 4 : 2; }
-bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
-
-// workgroups for `work_threads` grid-stride work items: at most kMaxGrid, and balanced -- every
-// workgroup gets the same number of sweeps (22016 blocks of work -> 18 sweeps x 1224 workgroups, not
-// 1280 workgroups of which 256 do one sweep more)
-int grid_for(int64_t work_threads)
-{
-    int64_t g = (work_threads + kThreads - 1) / kThreads;
-    if (g < 1) g = 1;
-    if (g <= kMaxGrid) return (int)g;
-    const int64_t sweeps = (g + kMaxGrid - 1) / kMaxGrid;
-    return (int)((g + sweeps - 1) / sweeps);
-}
-
 template <int DT, int NM, bool SFIRST, bool STOCH, bool DEQ_ONLY>
 int launch_fused_o(const FusedArgs& a, hipStream_t s)
 {
@@ -1472,39 +820,11 @@ int launch_fused_l(const FusedArgs& a, hipStream_t s)
     return launch_fused_o<DT, NM, SFIRST, STOCH, false>(a, s);
 }
 
-// resident capacity of the device for a kernel (workgroups), cached per kernel: the one-pass unstructured mode spins
-// on lower-numbered units, so its grid must not exceed what can run at once
-template <typename K>
-int resident_workgroups(K kernel)
-{
-    static int cus = 0;                                           // per process: one device model per node
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 64;
-    }
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kThreads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    return per_cu * cus;
-}
-
 template <int DT>
 int launch_fused_threshold(const FusedArgs& a, hipStream_t s)
 {
-    dim3 grid(grid_for(a.n_items)), block(kThreads);
+    const dim3 grid(grid_for(a.n_items)), block(kThreads);
     const bool deq_only = a.out_deq && !a.out_codes && !a.out_exp;
-    if (a.unit_status) {                                         // one-pass mode: units of 2048 items, co-resident workgroups only
-        const int64_t n_units = (a.n_items + 2047) / 2048;
-        int cap;
-        if (a.seed) cap = resident_workgroups(k_fused_flat<DT, -1, true, true, -1, false>);
-        else if (deq_only && a.lpb == 8) cap = resident_workgroups(k_fused_flat<DT, -1, true, false, 8, true>);
-        else if (deq_only && a.lpb == 4) cap = resident_workgroups(k_fused_flat<DT, -1, true, false, 4, true>);
-        else if (deq_only) cap = resident_workgroups(k_fused_flat<DT, -1, true, false, -1, true>);
-        else cap = resident_workgroups(k_fused_flat<DT, -1, true, false, -1, false>);
-        int64_t g = n_units < cap ? n_units : cap;                     // (equal units per workgroup, i.e. fewer workgroups, measured slower)
-        if (g > kMaxGrid) g = kMaxGrid;
-        grid = dim3((unsigned)(g < 1 ? 1 : g));
-    }
     if (a.seed) {
         hipLaunchKernelGGL((k_fused_flat<DT, -1, true, true, -1, false>), grid, block, 0, s, a);
     } else if (deq_only) {
@@ -1617,7 +937,7 @@ int bfpq_version(void) { return BFPQ_VERSION; }
 
 int bfpq_tune(int key, int value)
 {
-    if (key == BFPQ_TUNE_MAX_GRID && value >= 1 && value <= 65535) { g_max_grid = value; return 0; }
+    if (key == BFPQ_TUNE_MAX_GRID && value >= 1 && value <= 65535) { bfpq_g_max_grid = value; return 0; }
     if (key == BFPQ_TUNE_GEMM_ROW_TILES && (value == 0 || value == 1 || value == 2 || value == 4)) { bfpq_g_gemm_rt = value; return 0; }
     return BFPQ_E_ARG;
 }
@@ -1736,7 +1056,7 @@ int bfpq_quantize_nm(const void* in, void* out_deq, void* out_codes, int8_t* out
         a.lpb = block_size ? block_size / dtype_vec(dtype) : 0;
         a.mant_bits = mant_bits; a.N = N; a.code_bits = code_bits;
         a.force_slow = mant_bits > (dtype == BFPQ_F32 ? 24 : (dtype == BFPQ_F16 ? 11 : 8));
-        a.sel = nullptr; a.tie_counts = nullptr; a.tie_base = nullptr; a.unit_status = nullptr; a.unit_error = nullptr;
+        a.selws = nullptr;
         if (dtype == BFPQ_F32) return launch_fused<BFPQ_F32>(a, M, sparsify_first != 0, s);
         if (dtype == BFPQ_F16) return launch_fused<BFPQ_F16>(a, M, sparsify_first != 0, s);
         return launch_fused<BFPQ_BF16>(a, M, sparsify_first != 0, s);
@@ -1756,7 +1076,7 @@ int bfpq_quantize_nm(const void* in, void* out_deq, void* out_codes, int8_t* out
             a.lpb = block_size / dtype_vec(dtype);
             a.mant_bits = mant_bits; a.N = 0; a.code_bits = code_bits;
             a.force_slow = mant_bits > (dtype == BFPQ_F32 ? 24 : (dtype == BFPQ_F16 ? 11 : 8));
-            a.sel = nullptr; a.tie_counts = nullptr; a.tie_base = nullptr; a.unit_status = nullptr; a.unit_error = nullptr;
+            a.selws = nullptr;
             if (dtype == BFPQ_F32) return launch_fused<BFPQ_F32>(a, 0, true, s);
             if (dtype == BFPQ_F16) return launch_fused<BFPQ_F16>(a, 0, true, s);
             return launch_fused<BFPQ_BF16>(a, 0, true, s);
@@ -1790,157 +1110,15 @@ int bfpq_nm_sparsify(const void* in, void* out, int64_t rows, int64_t cols, int 
     return bfpq_quantize_nm(in, out, nullptr, nullptr, rows, cols, dtype, 0, 0, 0.0, N, M, 1, 0, 0, nullptr, nm4_lut, nullptr, stream);
 }
 
-int bfpq_select_passes(int dtype) { return dtype == BFPQ_F32 ? 3 : 1; }
-
-static int select_hist_impl(const void* in, int64_t numel, int dtype, int pass, const void* state, uint32_t* hist, void* stream,
-                            unsigned long long* zero_ptr, int64_t zero_n);
-
-int bfpq_select_hist(const void* in, int64_t numel, int dtype, int pass, const void* state, uint32_t* hist, void* stream)
-{
-    return select_hist_impl(in, numel, dtype, pass, state, hist, stream, nullptr, 0);
-}
-
-int bfpq_select_hist_prepare(const void* in, int64_t numel, int dtype, int pass, const void* state, uint32_t* hist,
-                             uint32_t* tie_ws, void* stream)
-{
-    if (!tie_ws || dtype < 0 || dtype > 2 || numel < 0) return BFPQ_E_ARG;
-    const int64_t n_items = numel / dtype_vec(dtype);
-    return select_hist_impl(in, numel, dtype, pass, state, hist, stream, reinterpret_cast<unsigned long long*>(tie_ws), (n_items + 2047) / 2048);
-}
-
-static int select_hist_impl(const void* in, int64_t numel, int dtype, int pass, const void* state, uint32_t* hist, void* stream,
-                            unsigned long long* zero_ptr, int64_t zero_n)
-{
-    if (!in || !state || !hist || dtype < 0 || dtype > 2 || numel < 0 || pass < 0 || pass >= bfpq_select_passes(dtype)) return BFPQ_E_ARG;
-    int shift, nbits;
-    select_digit(dtype, pass, &shift, &nbits);
-    const size_t lds = sizeof(uint32_t) << nbits;
-    const int threads = 1024;
-    int64_t g = (numel / dtype_vec(dtype) + threads - 1) / threads;
-    const int grid = (int)(g < 1 ? 1 : (g > 256 ? 256 : g));
-    hipStream_t s = (hipStream_t)stream;
-    const bfpq_select_state* st = (const bfpq_select_state*)state;
-    hipError_t err = hipSuccess;
-    if (dtype == BFPQ_F32) {
-        hipLaunchKernelGGL((k_select_hist<BFPQ_F32>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, pass == 0, st, hist, zero_ptr, zero_n);
-    } else if (dtype == BFPQ_F16) {
-        err = hipFuncSetAttribute((const void*)k_select_hist<BFPQ_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (err != hipSuccess) return (int)err;
-        hipLaunchKernelGGL((k_select_hist<BFPQ_F16>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, pass == 0, st, hist, zero_ptr, zero_n);
-    } else {
-        err = hipFuncSetAttribute((const void*)k_select_hist<BFPQ_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (err != hipSuccess) return (int)err;
-        hipLaunchKernelGGL((k_select_hist<BFPQ_BF16>), dim3(grid), dim3(threads), lds, s, in, numel, shift, nbits, pass == 0, st, hist, zero_ptr, zero_n);
-    }
-    return (int)hipGetLastError();
-}
-
-int bfpq_select_scan(int dtype, int pass, void* state, uint32_t* hist, int64_t k, void* stream)
-{
-    if (!state || !hist || dtype < 0 || dtype > 2 || pass < 0 || pass >= bfpq_select_passes(dtype) || k < 0) return BFPQ_E_ARG;
-    int shift, nbits;
-    select_digit(dtype, pass, &shift, &nbits);
-    const int last = pass == bfpq_select_passes(dtype) - 1, first = pass == 0;
-    bfpq_select_state* st = (bfpq_select_state*)state;
-    hipStream_t s = (hipStream_t)stream;
-    const int per = (1 << nbits) / 16 / 64;              // bins per lane: 32 (15-bit digit), 2 (11-bit), 0 -> 1 (9-bit)
-    if (per == 32) {
-        const size_t lds = 16 * 64 * 36 * sizeof(uint32_t);             // 144 KiB of the CU's 160
-        const hipError_t err = hipFuncSetAttribute((const void*)k_select_scan<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (err != hipSuccess) return (int)err;
-        hipLaunchKernelGGL(k_select_scan<32>, dim3(1), dim3(1024), lds, s, st, hist, shift, nbits, last, first, k);
-    }
-    else if (per == 2) hipLaunchKernelGGL(k_select_scan<2>, dim3(1), dim3(1024), 0, s, st, hist, shift, nbits, last, first, k);
-    else hipLaunchKernelGGL(k_select_scan<1>, dim3(1), dim3(1024), 0, s, st, hist, shift, nbits, last, first, k);
-    return (int)hipGetLastError();
-}
-
-int64_t bfpq_tie_workspace_elems(int64_t numel, int dtype)
-{
-    if (dtype < 0 || dtype > 2 || numel < 0) return BFPQ_E_ARG;
-    const int vec = dtype_vec(dtype);
-    const TieLayout l = tie_layout((numel + vec - 1) / vec);
-    return l.cpad + l.n_chunks * 64 + 64;      // + slack: the ragged last sweep of a consumer reads up to 3 tiles past the end
-}
-
-int bfpq_tie_count(const void* in, int64_t numel, int dtype, void* state, uint32_t* tie_ws, void* stream)
-{
-    if (!in || !state || !tie_ws || dtype < 0 || dtype > 2 || numel < 0) return BFPQ_E_ARG;
-    if (numel == 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
-    bfpq_select_state* st = (bfpq_select_state*)state;
-    const int vec = dtype_vec(dtype);
-    const int64_t n_items = (numel + vec - 1) / vec;
-    const bool fast = (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && numel % vec == 0;
-    int64_t g = (n_items + kThreads - 1) / kThreads;
-    const dim3 grid((unsigned)(g > 2048 ? 2048 : g)), block(kThreads);
-    const TieLayout lay = tie_layout(n_items);
-#define BFPQ_TC(DT) do { if (fast) hipLaunchKernelGGL((k_tie_count<DT, true>), grid, block, 0, s, in, numel, st, tie_ws); \
-                         else hipLaunchKernelGGL((k_tie_count<DT, false>), grid, block, 0, s, in, numel, st, tie_ws); } while (0)
-    if (dtype == BFPQ_F32) BFPQ_TC(BFPQ_F32); else if (dtype == BFPQ_F16) BFPQ_TC(BFPQ_F16); else BFPQ_TC(BFPQ_BF16);
-#undef BFPQ_TC
-    hipLaunchKernelGGL(k_tie_chunk_sum, dim3((unsigned)((lay.n_chunks + 3) / 4)), dim3(kThreads), 0, s, st, tie_ws, lay.n_tiles, lay.n_chunks, lay.cpad);
-    hipLaunchKernelGGL(k_tie_scan, dim3(1), dim3(1024), 0, s, st, tie_ws, lay.n_chunks);
-    return (int)hipGetLastError();
-}
-
-int bfpq_threshold_apply(const void* in, void* out, int64_t numel, int dtype, const void* state,
-                         const uint32_t* tie_ws, const int64_t* tie_base, void* stream)
-{
-    if (!in || !out || !state || !tie_ws || dtype < 0 || dtype > 2 || numel < 0) return BFPQ_E_ARG;
-    if (numel == 0) return 0;
-    hipStream_t s = (hipStream_t)stream;
-    const bfpq_select_state* st = (const bfpq_select_state*)state;
-    const int vec = dtype_vec(dtype);
-    const bool fast = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0 && numel % vec == 0;
-    const dim3 grid(grid_for((numel + vec - 1) / vec)), block(kThreads);
-#define BFPQ_TA(DT) do { if (fast) hipLaunchKernelGGL((k_threshold_apply<DT, true>), grid, block, 0, s, in, out, numel, st, tie_ws, tie_base); \
-                         else hipLaunchKernelGGL((k_threshold_apply<DT, false>), grid, block, 0, s, in, out, numel, st, tie_ws, tie_base); } while (0)
-    if (dtype == BFPQ_F32) BFPQ_TA(BFPQ_F32); else if (dtype == BFPQ_F16) BFPQ_TA(BFPQ_F16); else BFPQ_TA(BFPQ_BF16);
-#undef BFPQ_TA
-    return (int)hipGetLastError();
-}
-
-static int quantize_threshold_impl(const void* in, void* out_deq, void* out_codes, int8_t* out_exp,
-                                   int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits, double epsilon,
-                                   int code_bits, uint64_t stoch_seed, const uint8_t* exp_win,
-                                   const void* state, const uint32_t* counts, const int64_t* tie_base,
-                                   void* scratch, void* stream, bool onepass, bool status_prepared = false);
-
 int bfpq_quantize_threshold(const void* in, void* out_deq, void* out_codes, int8_t* out_exp,
                             int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits, double epsilon,
                             int code_bits, uint64_t stoch_seed, const uint8_t* exp_win,
-                            const void* state, const uint32_t* counts, const int64_t* tie_base,
-                            void* scratch, void* stream)
-{
-    return quantize_threshold_impl(in, out_deq, out_codes, out_exp, rows, cols, dtype, block_size, mant_bits, epsilon, code_bits,
-                                   stoch_seed, exp_win, state, counts, tie_base, scratch, stream, false);
-}
-
-int bfpq_quantize_threshold_onepass(const void* in, void* out_deq, void* out_codes, int8_t* out_exp,
-                                    int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits, double epsilon,
-                                    int code_bits, uint64_t stoch_seed, const uint8_t* exp_win,
-                                    void* state, uint32_t* tie_ws, int status_prepared, void* stream)
-{
-    if (dtype < 0 || dtype > 2 || rows < 0 || cols < 0 || block_size <= 0) return BFPQ_E_ARG;
-    if (rows * cols && !fused_shape_ok(rows, cols, dtype, block_size, 0, 0)) return BFPQ_E_UNSUPPORTED;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out_deq) | reinterpret_cast<uintptr_t>(out_codes) |
-                           reinterpret_cast<uintptr_t>(tie_ws)) & 15u) == 0;
-    if (!aligned) return BFPQ_E_UNSUPPORTED;
-    return quantize_threshold_impl(in, out_deq, out_codes, out_exp, rows, cols, dtype, block_size, mant_bits, epsilon, code_bits,
-                                   stoch_seed, exp_win, state, tie_ws, nullptr, nullptr, stream, true, status_prepared != 0);
-}
-
-static int quantize_threshold_impl(const void* in, void* out_deq, void* out_codes, int8_t* out_exp,
-                                   int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits, double epsilon,
-                                   int code_bits, uint64_t stoch_seed, const uint8_t* exp_win,
-                                   const void* state, const uint32_t* counts, const int64_t* tie_base,
-                                   void* scratch, void* stream, bool onepass, bool status_prepared)
+                            void* ws, void* scratch, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
     if (dtype < 0 || dtype > 2 || rows < 0 || cols < 0 || block_size <= 0) return BFPQ_E_ARG;
     if (rows * cols == 0) return 0;
-    if (!in || !state || !counts || !exp_win || (!out_deq && !out_codes && !out_exp)) return BFPQ_E_ARG;
+    if (!in || !ws || !exp_win || (!out_deq && !out_codes && !out_exp)) return BFPQ_E_ARG;
     if (mant_bits < 0 || mant_bits > 23) return BFPQ_E_ARG;
     if (out_codes && !(code_bits == 4 || code_bits == 8 || code_bits == 16)) return BFPQ_E_ARG;
     if (out_codes && ((code_bits == 4 && mant_bits > 3) || (code_bits == 8 && mant_bits > 7) || (code_bits == 16 && mant_bits > 15))) return BFPQ_E_ARG;
@@ -1955,20 +1133,7 @@ static int quantize_threshold_impl(const void* in, void* out_deq, void* out_code
         a.lpb = block_size / dtype_vec(dtype);
         a.mant_bits = mant_bits; a.N = 0; a.code_bits = code_bits;
         a.force_slow = mant_bits > (dtype == BFPQ_F32 ? 24 : (dtype == BFPQ_F16 ? 11 : 8));
-        a.sel = (const bfpq_select_state*)state; a.tie_counts = counts; a.tie_base = tie_base;
-        a.unit_status = nullptr; a.unit_error = nullptr;
-        if (onepass) {
-            // tie_ws doubles as the unit status array (8 B per unit of 2048 items <= the 4 B per 64 items it was sized for)
-            // and, in the unranked case, as a harmless target of the multi-pass kernel's tie reads
-            const int64_t n_units = (a.n_items + 2047) / 2048;
-            bfpq_select_state* st = (bfpq_select_state*)const_cast<void*>(state);
-            a.unit_status = reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(counts));
-            a.unit_error = reinterpret_cast<int*>(&st->reserved[1]);
-            if (!status_prepared) {
-                const hipError_t me = hipMemsetAsync(a.unit_status, 0, sizeof(unsigned long long) * (size_t)n_units, s);
-                if (me != hipSuccess) return (int)me;
-            }
-        }
+        a.selws = (SelWs*)ws;
         if (dtype == BFPQ_F32) return launch_fused_threshold<BFPQ_F32>(a, s);
         if (dtype == BFPQ_F16) return launch_fused_threshold<BFPQ_F16>(a, s);
         return launch_fused_threshold<BFPQ_BF16>(a, s);
@@ -1976,7 +1141,7 @@ static int quantize_threshold_impl(const void* in, void* out_deq, void* out_code
     void* tmp = out_deq ? out_deq : scratch;
     if (!tmp) return BFPQ_E_ARG;
     if (out_codes && code_bits == 4 && (block_size & 1)) return BFPQ_E_UNSUPPORTED;
-    int rc = bfpq_threshold_apply(in, tmp, rows * cols, dtype, state, counts, tie_base, stream);
+    int rc = bfpq_threshold_apply(in, tmp, rows * cols, dtype, ws, stream);
     if (rc) return rc;
     return launch_quant_rows(tmp, out_deq, out_codes, out_exp, rows, cols, dtype, block_size, mant_bits, eps_dt, code_bits, stoch_seed, exp_win, s);
 }

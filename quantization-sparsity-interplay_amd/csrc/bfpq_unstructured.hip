@@ -1,0 +1,418 @@
+// bfpq_unstructured.hip -- the unstructured (global magnitude threshold) path of libbfpq.so: histogram, resolve and
+// prune-only apply launches + their C-ABI entry points (include/bfpq.h).  The fused prune+quantize apply is
+// k_fused_flat<.., -1, ..> in bfpq_kernels.hip.  Reference: src/transformers/bfp/bfp_ops.py:61-71.
+#include <hip/hip_runtime.h>
+#include "bfpq.h"
+#include "bfpq_common.h"
+#include "bfpq_device.h"
+
+using namespace bfpq;
+using namespace bfpq_dev;
+
+namespace {
+
+// Build with EXTRA=-DBFPQ_STAMPS for phase timing (tools_dev/stamps.py): thread 0 of every workgroup records the
+// constant 100 MHz clock at named points; never in the product build.
+#ifdef BFPQ_STAMPS
+__device__ unsigned long long g_stamps[3][512][8];
+#define STAMP(kern, idx) do { if (threadIdx.x == 0 && blockIdx.x < 512) { unsigned long long t_; \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_stamps[kern][blockIdx.x][idx] = t_; } } while (0)
+#else
+#define STAMP(kern, idx) do { } while (0)
+#endif
+
+// Launch 1: histogram of the current digit.  One workgroup per flat-contiguous segment (see the block comment at ThrCtx);
+// LDS histogram (32 768 bins = 128 KB for 16-bit keys), non-zero bins flushed by integer atomics (deterministic).  On the
+// pass that decides the threshold the workgroup also leaves a window of its private histogram in the workspace.
+template <int DT, bool FAST>
+__global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int64_t numel, int pass, int shift, int nbits, int first, int last,
+                                                             SelWs* ws, uint32_t* hist_ext, int64_t k, int64_t numel_global)
+{
+    using T = Traits<DT>;
+    constexpr int VEC = T::VEC;
+    extern __shared__ uint32_t s_hist[];
+    uint32_t* hist = hist_ext ? hist_ext : ws->hist[pass][0];
+    __shared__ __attribute__((aligned(16))) uint32_t s_coarse[kCoarseBins];
+    __shared__ uint32_t s_res[4];
+    const int t = threadIdx.x;
+    const int nbins = 1 << nbits;
+    STAMP(0, 0);
+    for (int i = t; i < nbins / 4; i += kSelThreads) reinterpret_cast<uint4*>(s_hist)[i] = make_uint4(0, 0, 0, 0);
+    if (t < kCoarseBins) s_coarse[t] = 0;
+    __syncthreads();
+    const uint32_t pmask = first ? 0u : ws->st.prefix_mask, pval = first ? 0u : ws->st.prefix;   // pass 0 reads no state
+    const uint32_t dmask = (uint32_t)nbins - 1u;
+    const int64_t n_items = (numel + VEC - 1) / VEC;
+    const SegGeom g = seg_geom(n_items);
+    const int64_t i0 = (int64_t)blockIdx.x * g.L, i1 = i0 + g.L < n_items ? i0 + g.L : n_items;
+    if constexpr (FAST && VEC == 8) {
+        // 16-bit dtypes: one pass over the whole 15-bit key (shift 0, no prefix to match): two keys per packed and/min,
+        // unconditional LDS atomics; one-ahead prefetch with a clamped, unconditional load
+        const uint32_t absm = T::ABS | (T::ABS << 16), nanc = (T::INF + 1u) | ((T::INF + 1u) << 16);
+        const int64_t lastv = n_items - 1;
+        int64_t item = i0 + t;
+        uint4 v = reinterpret_cast<const uint4*>(in)[item < lastv ? item : lastv];
+        for (; item < i1; item += kSelThreads) {
+            const int64_t pf = item + kSelThreads;
+            const uint4 nv = reinterpret_cast<const uint4*>(in)[pf < lastv ? pf : lastv];
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t k2 = pk_min_i16_s(d[j] & absm, nanc);
+                atomicAdd(&s_hist[k2 & 0xffffu], 1u);
+                atomicAdd(&s_hist[k2 >> 16], 1u);
+            }
+            v = nv;
+        }
+    } else {
+        int64_t item = i0 + t;
+        uint32_t cur[VEC], nxt[VEC];
+        sweep_load<DT, FAST>(in, item, n_items, numel, cur);
+        for (; item < i1; item += kSelThreads) {
+            sweep_load<DT, FAST>(in, item + kSelThreads, n_items, numel, nxt);
+#pragma unroll
+            for (int j = 0; j < VEC; j++) {
+                const uint32_t key = mag_key<DT>(cur[j]);
+                const bool real = FAST || item * VEC + j < numel;
+                if (real && (key & pmask) == pval) atomicAdd(&s_hist[(key >> shift) & dmask], 1u);
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; j++) cur[j] = nxt[j];
+        }
+    }
+    STAMP(0, 1);
+    __syncthreads();
+    STAMP(0, 2);
+    // flush of the non-zero bins by integer atomics (deterministic) into this workgroup's COPY of the histogram: with
+    // all workgroups adding into one copy every hot address takes 256 serialised adds (~3 us behind the streaming loop)
+    hist += (size_t)(blockIdx.x % BFPQ_SELECT_HIST_COPIES) * BFPQ_SELECT_HIST_ENTRIES;
+    for (int i = t; i < nbins; i += kSelThreads) {
+        const uint32_t c = s_hist[i];
+        if (c) atomicAdd(&hist[i], c);
+    }
+    STAMP(0, 3);
+    if (!last && nbits != 15) return;
+    if (nbits != 15) {                                      // fp32, last digit (512 bins): the whole private histogram
+        for (int i = t; i < nbins; i += kSelThreads) ws->windows[blockIdx.x][i] = s_hist[i];
+        if (t == 0) ws->seg_win[blockIdx.x] = 0u;
+        return;
+    }
+    // coarse histogram (256 bins of 128): four threads per coarse bin, each sums 32 bins in a rotated order (bank = 4 x
+    // ((j + q) mod 8) + r: two lanes per bank), then a quad reduction
+    {
+        const int q = t >> 2, r = t & 3;
+        uint32_t sum = 0;
+#pragma unroll 8
+        for (int j = 0; j < 32; j++) sum += s_hist[q * 128 + ((j + q) & 31) * 4 + r];
+        sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+        sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+        if (r == 0) { s_coarse[q] = sum; if (sum) atomicAdd(&hist[kFineBins + q], sum); }
+    }
+    STAMP(0, 4);
+    if (!last) return;
+    __syncthreads();
+    // window: the 16 coarse bins (2048 bins) around the one that holds the segment's own k-quantile.  The first wave
+    // finds it: four coarse sums per lane, one wave scan.
+    if (t < 64) {
+        const uint4 c4 = *reinterpret_cast<const uint4*>(&s_coarse[t * 4]);
+        const uint32_t mine = c4.x + c4.y + c4.z + c4.w;
+        const uint32_t incl = wave_incl_scan(mine);
+        const uint32_t seg_elems = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint64_t target = numel_global > 0 ? (uint64_t)((double)seg_elems * ((double)k / (double)numel_global)) : 0ull;   // (an anchor, not a count)
+        if (seg_elems && target >= seg_elems) target = seg_elems - 1;
+        const uint32_t excl = incl - mine;
+        if (t == 0) s_res[0] = 0;
+        if (mine && excl <= target && target < (uint64_t)excl + mine) {
+            uint32_t e = excl;
+            int A = t * 4;
+            if (target >= e + c4.x) { e += c4.x; A++; if (target >= e + c4.y) { e += c4.y; A++; if (target >= e + c4.z) A++; } }
+            int clo = A - kWinBins / 256;
+            clo = clo < 0 ? 0 : (clo > kCoarseBins - kWinBins / 128 ? kCoarseBins - kWinBins / 128 : clo);
+            uint32_t inside = 0;
+            for (int j = 0; j < kWinBins / 128; j++) inside += s_coarse[clo + j];
+            s_res[0] = (uint32_t)clo * 128u;
+            ws->seg_win[blockIdx.x] = ((uint32_t)clo * 128u) | (inside != seg_elems ? 0x80000000u : 0u);
+        }
+    }
+    __syncthreads();
+    const int lo = (int)s_res[0];
+    ws->windows[blockIdx.x][t] = s_hist[lo + t];
+    ws->windows[blockIdx.x][kSelThreads + t] = s_hist[lo + kSelThreads + t];
+    STAMP(0, 5);
+}
+
+// Launch 2: one workgroup (256 threads) per segment, every one of them repeats the (tiny) selection: which digit holds
+// the k-th smallest key.  hist_all: n_hists histograms of BFPQ_SELECT_HIST_ENTRIES words -- BFPQ_SELECT_HIST_COPIES per
+// rank, rank-major (an all-gather of the per-rank buffers; one rank: the local buffer) -- summed on the fly; on the deciding
+// pass the per-rank counts of the threshold bin also give, without a second exchange, the ties that lower ranks hold.
+// On the deciding pass: tie count of the own segment (window, or recount), piece counts of the segment that holds the
+// cut.  Zeroes zero_buf (multi-GPU: the local histogram buffer, which this launch does not read -- it reads the gathered copy).
+constexpr int kResThreads = 256;
+template <int DT, bool FAST>
+__global__ void __launch_bounds__(kResThreads) k_select_resolve(const void* in, int64_t numel, int pass, int shift, int nbits, int first, int last,
+                                                                const uint32_t* hist_all, int n_ranks, int rank, int64_t k,
+                                                                SelWs* ws, uint32_t* zero_buf, int own_hist)
+{
+    constexpr int VEC = Traits<DT>::VEC;
+    constexpr int NC = BFPQ_SELECT_HIST_COPIES;
+    __shared__ uint32_t s_part[16];
+    __shared__ uint32_t s_res[12];
+    const int t = threadIdx.x;
+    bfpq_select_state* st = &ws->st;
+    STAMP(1, 0);
+    if (own_hist) { hist_all = ws->hist[pass][0]; zero_buf = nullptr; n_ranks = 1; rank = 0; }
+    const int n_hists = n_ranks * NC;
+    const int64_t n_items = (numel + VEC - 1) / VEC;
+    const SegGeom g = seg_geom(n_items);
+    // loads that depend on nothing go first: this segment-window word, the state of the previous pass
+    const uint32_t wb = (last && t < g.G) ? ws->seg_win[t] : 0u;
+    const uint32_t k_rem = first ? (uint32_t)k : (uint32_t)st->k_rem;
+    const uint32_t prefix0 = first ? 0u : st->prefix, pmask0 = first ? 0u : st->prefix_mask;
+    const int64_t k0 = first ? k : st->k;
+    auto sum_h = [&](int idx) { uint32_t s = 0; for (int r = 0; r < n_hists; r++) s += hist_all[(size_t)r * BFPQ_SELECT_HIST_ENTRIES + idx]; return s; };
+    if (t < 12) s_res[t] = 0;                               // (k_rem == 0: digit 0, nothing in front of it)
+    uint32_t total;
+    if (nbits == 15) {
+        uint32_t v = sum_h(kFineBins + t);                  // 256 coarse bins, one per thread
+        uint32_t excl = block_excl_scan(v, s_part, &total);                  // (its barriers also order the s_res reset)
+        if (v && excl < k_rem && k_rem <= excl + v) { s_res[0] = (uint32_t)t; s_res[1] = excl; }
+        __syncthreads();
+        const int C = (int)s_res[0];
+        const uint32_t before = s_res[1];
+        v = t < 128 ? sum_h(C * 128 + t) : 0u;
+        excl = before + block_excl_scan(v, s_part, &total);
+        if (v && excl < k_rem && k_rem <= excl + v) { s_res[2] = (uint32_t)(C * 128 + t); s_res[3] = excl; s_res[4] = v; }
+    } else {
+        const int nbins = 1 << nbits;                       // 2048 or 512: eight or two contiguous bins per thread
+        const int per = nbins / kResThreads;
+        uint32_t v[8], mine = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { v[j] = j < per ? sum_h(t * per + j) : 0u; mine += v[j]; }
+        uint32_t excl = block_excl_scan(mine, s_part, &total);
+        if (mine && excl < k_rem && k_rem <= excl + mine) {
+            int j = 0;
+            while (j < per - 1 && k_rem > excl + v[j]) { excl += v[j]; j++; }
+            s_res[2] = (uint32_t)(t * per + j); s_res[3] = excl; s_res[4] = v[j];
+        }
+    }
+    __syncthreads();
+    STAMP(1, 1);
+    const uint32_t digit = s_res[2], run = s_res[3], cnt = s_res[4];
+    const uint32_t prefix = prefix0 | (digit << shift);
+    // the buffer the next histogram launch accumulates into
+    if (zero_buf)
+        for (int i = blockIdx.x * kResThreads + t; i < NC * BFPQ_SELECT_HIST_ENTRIES / 4; i += gridDim.x * kResThreads)
+            reinterpret_cast<uint4*>(zero_buf)[i] = make_uint4(0, 0, 0, 0);
+    if (!last) {
+        if (blockIdx.x == 0 && t == 0) {
+            st->prefix = prefix; st->prefix_mask = pmask0 | (((1u << nbits) - 1u) << shift);
+            st->k_rem = (int64_t)(k_rem - run); st->k = k0; st->done = 0;
+        }
+        return;
+    }
+    const uint32_t tau = prefix, need = k_rem - run;
+    uint32_t tie_base = 0;
+    for (int r = 0; r < rank * NC; r++) tie_base += hist_all[(size_t)r * BFPQ_SELECT_HIST_ENTRIES + digit];
+    const int W = nbits == 15 ? kWinBins : (1 << nbits);
+    // tie count of every segment from its window
+    uint32_t tc = 0;
+    int miss = 0;
+    if (t < g.G) {
+        const uint32_t rel = digit - (wb & 0x7fffffffu);
+        if (rel < (uint32_t)W) tc = ws->windows[t][rel];
+        else if (wb >> 31) miss = 1;
+    }
+    STAMP(1, 2);
+    const int any_miss = __syncthreads_or(miss);
+    STAMP(1, 3);
+    const bool mine_seg = t == (int)blockIdx.x;
+    if (mine_seg) s_res[5] = (uint32_t)miss;
+    uint32_t local_total;
+    const uint32_t excl = block_excl_scan(tc, s_part, &local_total);        // (barriers: s_res[5] visible)
+    if (!any_miss) {
+        if (mine_seg) ws->seg_ties[t] = tc;
+        const bool ranked = k0 > 0 && need > 0 && need < cnt;
+        const int64_t local_need = (int64_t)need - tie_base;
+        if (ranked && local_need > 0 && local_need < (int64_t)local_total) {
+            if (tc && (int64_t)excl <= local_need && local_need < (int64_t)excl + tc) { s_res[6] = (uint32_t)t; s_res[7] = (uint32_t)(local_need - excl); }
+            __syncthreads();
+            const int B = (int)s_res[6];
+            if (s_res[7] != 0) {
+                // ties per piece of segment B: one wave per piece, the grid's waves share the pieces
+                const int64_t b0 = (int64_t)B * g.L, b1 = b0 + g.L < n_items ? b0 + g.L : n_items;
+                const PieceGeom pg = piece_geom(b1 - b0);
+                const int lane = t & 63;
+                for (int q = blockIdx.x * (kResThreads / 64) + (t >> 6); q < pg.n; q += gridDim.x * (kResThreads / 64)) {
+                    const int64_t it0 = b0 + (int64_t)q * pg.tiles_per * 64;
+                    int64_t it1 = it0 + pg.tiles_per * 64;
+                    if (it1 > b1) it1 = b1;
+                    uint32_t c = 0;
+                    for (int64_t it = it0 + lane; it < it1; it += 64) {
+                        uint32_t r[VEC];
+                        sweep_load<DT, FAST>(in, it, n_items, numel, r);
+                        c += count_eq<DT>(r, tau);
+                    }
+                    c = wave_sum(c);
+                    if (lane == 0) ws->piece_counts[q] = c;
+                }
+            }
+        }
+    } else {
+        // some segment's window does not cover the threshold: every such segment counts its ties again (its own
+        // workgroup, so no workgroup waits for another); the apply launch then ranks the whole segment that holds the cut
+        if (s_res[5]) {
+            const int64_t i0 = (int64_t)blockIdx.x * g.L, i1 = i0 + g.L < n_items ? i0 + g.L : n_items;
+            uint32_t c = 0;
+            for (int64_t it = i0 + t; it < i1; it += kResThreads) {
+                uint32_t r[VEC];
+                sweep_load<DT, FAST>(in, it, n_items, numel, r);
+                c += count_eq<DT>(r, tau);
+            }
+            uint32_t tot;
+            (void)block_excl_scan(c, s_part, &tot);
+            if (t == 0) ws->seg_ties[blockIdx.x] = tot;
+        } else if (mine_seg) ws->seg_ties[t] = tc;
+    }
+    STAMP(1, 4);
+    if (blockIdx.x == 0 && t == 0) {
+        st->prefix = prefix; st->prefix_mask = pmask0 | (((1u << nbits) - 1u) << shift);
+        st->k_rem = (int64_t)need; st->tau = tau; st->done = 1;
+        st->need = (int64_t)need; st->ties = (int64_t)cnt; st->k = k0;
+        st->tie_base = (int64_t)tie_base; st->flags = (any_miss ? 0u : 1u) | (own_hist ? 2u : 0u); st->reserved = 0;
+    }
+}
+
+// Launch 3 (prune only: q -> s order, ragged shapes; the fused quantizer is k_fused_flat<.., -1, ..>)
+template <int DT, bool FAST>
+__global__ void __launch_bounds__(kThreads) k_threshold_apply(const void* in, void* out, int64_t numel, SelWs* ws)
+{
+    using raw_t = typename Traits<DT>::raw_t;
+    constexpr int VEC = Traits<DT>::VEC;
+    __shared__ uint32_t s_part[16];
+    __shared__ uint32_t s_res[8];
+    const int64_t n_items = (numel + VEC - 1) / VEC;
+    const int64_t n_round = (n_items + 63) / 64 * 64;
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    uint32_t cur[VEC], nxt[VEC];
+    sweep_load<DT, FAST>(in, item, n_items, numel, cur);
+    ThrCtx t;
+    thr_setup<DT>(t, ws, in, numel, n_items, s_part, s_res);
+    for (; item < n_round; item += stride) {                   // wave-uniform trip count
+        sweep_load<DT, FAST>(in, item + stride, n_items, numel, nxt);
+        const bool valid = item < n_items;
+        const uint32_t prune = thr_prune_bits<DT, FAST>(cur, valid, item, t);
+        if (valid) {
+            const int64_t e0 = item * VEC;
+            if constexpr (FAST) {
+                uint32_t r[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; j++) r[j] = ((prune >> j) & 1u) ? 0u : cur[j];
+                uint4 o;
+                if constexpr (VEC == 4) o = make_uint4(r[0], r[1], r[2], r[3]);
+                else o = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
+                reinterpret_cast<uint4*>(out)[item] = o;
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; j++)
+                    if (e0 + j < numel) reinterpret_cast<raw_t*>(out)[e0 + j] = ((prune >> j) & 1u) ? (raw_t)0 : (raw_t)cur[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; j++) cur[j] = nxt[j];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+#ifdef BFPQ_STAMPS
+int bfpq_debug_stamps(void* host_dst) { return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
+#endif
+
+int bfpq_select_passes(int dtype) { return dtype == BFPQ_F32 ? 3 : 1; }
+
+int64_t bfpq_select_ws_bytes(void) { return (int64_t)sizeof(SelWs); }
+
+// numel and k are counted in 32 bits on the device
+static bool select_args_ok(const void* in, int64_t numel, int dtype, int pass, int64_t k, const void* ws)
+{
+    return ws && dtype >= 0 && dtype <= 2 && numel >= 0 && (in || numel == 0) && pass >= 0 && pass < bfpq_select_passes(dtype) && k >= 0;
+}
+
+int bfpq_select_hist(const void* in, int64_t numel, int dtype, int pass, int64_t k, int64_t numel_global,
+                     void* ws, uint32_t* hist, void* stream)
+{
+    if (!select_args_ok(in, numel, dtype, pass, k, ws) || numel_global < numel || k > numel_global) return BFPQ_E_ARG;
+    if (numel_global >= ((int64_t)1 << 32)) return BFPQ_E_UNSUPPORTED;
+    if (numel == 0) return 0;
+    int shift, nbits;
+    select_digit(dtype, pass, &shift, &nbits);
+    const size_t lds = sizeof(uint32_t) << nbits;
+    const int vec = dtype_vec(dtype);
+    const SegGeom g = seg_geom((numel + vec - 1) / vec);
+    const bool fast = (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && numel % vec == 0;
+    const int first = pass == 0, last = pass == bfpq_select_passes(dtype) - 1;
+    hipStream_t s = (hipStream_t)stream;
+    SelWs* w = (SelWs*)ws;
+#define BFPQ_SH(DT, F) do { \
+        if (lds > 48 * 1024) { \
+            const hipError_t err = hipFuncSetAttribute((const void*)k_select_hist<DT, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (err != hipSuccess) return (int)err; \
+        } \
+        hipLaunchKernelGGL((k_select_hist<DT, F>), dim3(g.G), dim3(kSelThreads), lds, s, in, numel, pass, shift, nbits, first, last, w, hist, k, numel_global); \
+    } while (0)
+    if (dtype == BFPQ_F32) { if (fast) BFPQ_SH(BFPQ_F32, true); else BFPQ_SH(BFPQ_F32, false); }
+    else if (dtype == BFPQ_F16) { if (fast) BFPQ_SH(BFPQ_F16, true); else BFPQ_SH(BFPQ_F16, false); }
+    else { if (fast) BFPQ_SH(BFPQ_BF16, true); else BFPQ_SH(BFPQ_BF16, false); }
+#undef BFPQ_SH
+    return (int)hipGetLastError();
+}
+
+int bfpq_select_resolve(const void* in, int64_t numel, int dtype, int pass, int64_t k,
+                        const uint32_t* hist_all, int n_ranks, int rank, void* ws, uint32_t* zero_hist, void* stream)
+{
+    if (!select_args_ok(in, numel, dtype, pass, k, ws) || (hist_all && (n_ranks < 1 || rank < 0 || rank >= n_ranks))) return BFPQ_E_ARG;
+    if (k >= ((int64_t)1 << 32) || numel >= ((int64_t)1 << 32)) return BFPQ_E_UNSUPPORTED;
+    if (numel == 0) return 0;                                 // an empty slab has nothing to prune (its histogram stayed zero)
+    int shift, nbits;
+    select_digit(dtype, pass, &shift, &nbits);
+    const int vec = dtype_vec(dtype);
+    const SegGeom g = seg_geom((numel + vec - 1) / vec);
+    const bool fast = (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && numel % vec == 0;
+    const int first = pass == 0, last = pass == bfpq_select_passes(dtype) - 1;
+    hipStream_t s = (hipStream_t)stream;
+    SelWs* w = (SelWs*)ws;
+#define BFPQ_SR(DT, F) hipLaunchKernelGGL((k_select_resolve<DT, F>), dim3(g.G), dim3(kResThreads), 0, s, in, numel, pass, shift, nbits, first, last, \
+                                          hist_all, n_ranks, rank, k, w, zero_hist, hist_all ? 0 : 1)
+    if (dtype == BFPQ_F32) { if (fast) BFPQ_SR(BFPQ_F32, true); else BFPQ_SR(BFPQ_F32, false); }
+    else if (dtype == BFPQ_F16) { if (fast) BFPQ_SR(BFPQ_F16, true); else BFPQ_SR(BFPQ_F16, false); }
+    else { if (fast) BFPQ_SR(BFPQ_BF16, true); else BFPQ_SR(BFPQ_BF16, false); }
+#undef BFPQ_SR
+    return (int)hipGetLastError();
+}
+
+int bfpq_select_reset(void* ws, void* stream)
+{
+    if (!ws) return BFPQ_E_ARG;
+    return (int)hipMemsetAsync(((SelWs*)ws)->hist, 0, sizeof(((SelWs*)ws)->hist), (hipStream_t)stream);
+}
+
+int bfpq_threshold_apply(const void* in, void* out, int64_t numel, int dtype, void* ws, void* stream)
+{
+    if (!in || !out || !ws || dtype < 0 || dtype > 2 || numel < 0) return BFPQ_E_ARG;
+    if (numel == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    SelWs* w = (SelWs*)ws;
+    const int vec = dtype_vec(dtype);
+    const bool fast = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0 && numel % vec == 0;
+    const dim3 grid(grid_for((numel + vec - 1) / vec)), block(kThreads);
+#define BFPQ_TA(DT) do { if (fast) hipLaunchKernelGGL((k_threshold_apply<DT, true>), grid, block, 0, s, in, out, numel, w); \
+                         else hipLaunchKernelGGL((k_threshold_apply<DT, false>), grid, block, 0, s, in, out, numel, w); } while (0)
+    if (dtype == BFPQ_F32) BFPQ_TA(BFPQ_F32); else if (dtype == BFPQ_F16) BFPQ_TA(BFPQ_F16); else BFPQ_TA(BFPQ_BF16);
+#undef BFPQ_TA
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

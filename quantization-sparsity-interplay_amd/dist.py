@@ -6,8 +6,8 @@ No counterpart in the reference (it has no collectives on this path, SURVEY §2.
 
 Why rows: every HBFP block and every N:M group lies inside one row (bfp_ops.py:50-59, :79-91), so a
 contiguous slab of rows is an independent unit -- quantize / N:M need NO data-path collective.  The
-only real exchange is unstructured pruning's global k-th magnitude: one all-reduce of the radix
-histogram per pass (128 KB) and one all-gather of per-rank tie totals (8 B per rank).  An all-gather of
+only real exchange is unstructured pruning's global k-th magnitude: one all-gather of the per-rank radix
+histograms per pass (132 KB per rank), from which every rank also reads the ties lower ranks hold.  An all-gather of
 the result happens only when the caller asks for the tensor whole; on a fully connected xGMI node it
 maps to concurrent point-to-point sends, so packed codes (2.9 MB per rank at the headline shape) or
 the dequantised slab (11.3 MB) move at per-link rate on all 7 links at once.
@@ -48,32 +48,31 @@ def all_gather_rows(local, rows_total, group=None):
     return out[:rows_total]
 
 
-def _hist_allreduce(group):
+def _hist_allgather(group):
+    """the one exchange of the unstructured path: every rank's radix histogram (132 KB) to every rank.  The resolve launch
+    sums them for the global threshold and reads, from the per-rank counts of the threshold bin, how many ties lower
+    ranks hold -- so there is no second (tie-count) exchange."""
     def fn(hist):
-        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
-    return fn
-
-
-def _tie_exchange(group):
-    def fn(local_total):
-        """local_total: int64[1] on the compute device -> int64[1]: ties held by lower ranks"""
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        allt = torch.empty(world, dtype=torch.int64, device=local_total.device)
-        dist.all_gather_into_tensor(allt, local_total.contiguous(), group=group)
-        return allt[:rank].sum().reshape(1)
+        allh = torch.empty(world * hist.numel(), dtype=hist.dtype, device=hist.device)
+        dist.all_gather_into_tensor(allh, hist.contiguous().view(-1), group=group)
+        return allh.view(world, hist.numel()), world, rank
     return fn
 
 
 def unstructured_sparsity_sharded(local, sparsity_frac, numel_global, group=None, engine=None):
     """_unstructured_sparsity (bfp_ops.py:61-71) of a row-sharded tensor: one threshold for the whole
-    tensor, k = int(numel_global * frac), ties pruned lowest global flat index first.
+    tensor, k = int(numel_global * frac), ties pruned lowest global flat index first.  A rank whose slab is
+    empty (ragged split) still joins the histogram gather.
     engine: object with select_threshold / threshold_apply / workspace (default: the HIP engine)."""
     assert (sparsity_frac > 0)
     eng = engine or _NativeEngine()
     k = int(numel_global * sparsity_frac)
     ws = eng.workspace(local.device)
-    eng.select_threshold(local, k, ws, allreduce=_hist_allreduce(group))
-    return eng.threshold_apply(local, ws, exchange_ties=_tie_exchange(group)).view(local.shape)
+    eng.select_threshold(local, k, ws, numel_global=numel_global, allgather=_hist_allgather(group))
+    if local.numel() == 0:
+        return local.clone()
+    return eng.threshold_apply(local, ws).view(local.shape)
 
 
 class _NativeEngine:
@@ -82,6 +81,10 @@ class _NativeEngine:
 
     select_threshold = staticmethod(native.select_threshold)
     threshold_apply = staticmethod(native.threshold_apply)
+
+    @staticmethod
+    def quantize_threshold(t, ws, block_size, mant_bits, epsilon, seed):
+        return native.quantize_threshold(t, ws, block_size, mant_bits, epsilon, stoch_seed=seed)[0]
 
 
 def float_to_bfp_blocked_sharded(local, rows_total, group=None, gather=False, compute=None, engine=None,
@@ -94,9 +97,28 @@ def float_to_bfp_blocked_sharded(local, rows_total, group=None, gather=False, co
                                         bfp_args.get('grad_sparsity'), identifier)
     if sparsity and bfp_args.get('sparsity_mode') == 'unstructured':
         # the one path with a real exchange step: global threshold
-        numel_global = rows_total * (local.numel() // max(local.shape[0], 1))
+        cols = 1
+        for d in local.shape[1:]:
+            cols *= int(d)
+        numel_global = rows_total * cols
         dense = dict(bfp_args, in_sparsity=False, w_sparsity=False, grad_sparsity=False)
-        if bfp_args.get('first') == 's':
+        eng = engine or _NativeEngine()
+        fused = (bfp_args.get('first') == 's' and bfp_args.get('sparsity_num_format') == 'bfp' and hasattr(eng, 'quantize_threshold')
+                 and compute is bfp_ops.float_to_bfp_blocked)
+        if fused:
+            # threshold, then prune + quantize in ONE pass over the slab (as on a single device)
+            assert (bfp_args['sparsity_frac'] > 0)
+            ws = eng.workspace(local.device)
+            eng.select_threshold(local, int(numel_global * bfp_args['sparsity_frac']), ws, numel_global=numel_global,
+                                 allgather=_hist_allgather(group))
+            if local.numel() == 0:
+                out = local.clone()
+            else:
+                mb = bfp_args['weight_mant_bits'] if bfp_args.get('sgd_update') else bfp_args['mant_bits']
+                seed = bfp_ops._seed_for(bfp_args['rounding_mode'])
+                out = bfp_ops._stoc_dtype(eng.quantize_threshold(local, ws, bfp_args['block_size'], mb, bfp_args['epsilon'], seed)
+                                          .view(local.shape), bfp_args['rounding_mode'])
+        elif bfp_args.get('first') == 's':
             pruned = unstructured_sparsity_sharded(local, bfp_args['sparsity_frac'], numel_global, group, engine)
             out = compute(pruned, **dense, identifier=identifier)
         else:

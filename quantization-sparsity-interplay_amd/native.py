@@ -22,14 +22,10 @@ DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 EXP_WIN_ENTRIES = 320
 NM4_LUT_ENTRIES = 729
 NM8_LUT_ENTRIES = 1 << 24
-# Single-device unstructured s->q through bfpq_quantize_threshold_onepass (units in registers/LDS + decoupled look-back for the
-# tie ranks, no tie-count pass).  Bit-identical to the multi-pass route (tested), but measured a wash on MI355X ([5120,5120]
-# bf16: 61.9 vs 64.5 us; [13824,5120]: 129 vs 125 us) and it is a spin-wait kernel, so it is opt-in; the default stays the
-# multi-pass route (tie count + chunk sums + scan + apply as separate launches), which is also what the multi-GPU path uses.
-ONEPASS_UNSTRUCTURED = os.environ.get("BFPQ_ONEPASS", "0") == "1"
 USE_NM8_TABLE = True               # False: N:8 groups with straddling ties replay nth_element in the kernel (tests)
 SELECT_STATE_BYTES = 64
-SELECT_HIST_BINS = 32768
+SELECT_HIST_ENTRIES = 32768 + 256
+SELECT_HIST_COPIES = 8
 
 
 class NativeUnavailable(RuntimeError):
@@ -37,7 +33,7 @@ class NativeUnavailable(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, _LIB_NAME)
+    return os.environ.get("BFPQ_LIB") or os.path.join(_HERE, _LIB_NAME)     # (BFPQ_LIB: an instrumented build, tools_dev/)
 
 
 def build_library(force=False):
@@ -72,8 +68,6 @@ def load_library():
         L.bfpq_exp_window_host.argtypes = [i32, vp]
         L.bfpq_nm4_lut_host.argtypes = [i32, vp]
         L.bfpq_nm8_lut_host.argtypes = [i32, vp]
-        L.bfpq_quantize_threshold_onepass.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, dbl, i32, u64, vp, vp, vp, i32, vp]
-        L.bfpq_select_hist_prepare.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp]
         L.bfpq_compact24.argtypes = [vp, vp, vp, i64, vp, vp]
         L.bfpq_expand24.argtypes = [vp, vp, vp, i64, vp]
         L.bfpq_nm_prune_mask_host.argtypes = [vp, i32, i32]
@@ -82,13 +76,13 @@ def load_library():
         L.bfpq_is_fused.argtypes = [i64, i64, i32, i32, i32, i32]
         L.bfpq_nm_sparsify.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp]
         L.bfpq_select_passes.argtypes = [i32]
-        L.bfpq_tie_workspace_elems.argtypes = [i64, i32]
-        L.bfpq_tie_workspace_elems.restype = i64
-        L.bfpq_select_hist.argtypes = [vp, i64, i32, i32, vp, vp, vp]
-        L.bfpq_select_scan.argtypes = [i32, i32, vp, vp, i64, vp]
-        L.bfpq_tie_count.argtypes = [vp, i64, i32, vp, vp, vp]
-        L.bfpq_threshold_apply.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp]
-        L.bfpq_quantize_threshold.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, dbl, i32, u64, vp, vp, vp, vp, vp, vp]
+        L.bfpq_select_ws_bytes.argtypes = []
+        L.bfpq_select_ws_bytes.restype = i64
+        L.bfpq_select_hist.argtypes = [vp, i64, i32, i32, i64, i64, vp, vp, vp]
+        L.bfpq_select_resolve.argtypes = [vp, i64, i32, i32, i64, vp, i32, i32, vp, vp, vp]
+        L.bfpq_threshold_apply.argtypes = [vp, vp, i64, i32, vp, vp]
+        L.bfpq_select_reset.argtypes = [vp, vp]
+        L.bfpq_quantize_threshold.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, dbl, i32, u64, vp, vp, vp, vp]
         L.bfpq_int_workspace_elems.argtypes = [i64]
         L.bfpq_int_workspace_elems.restype = i64
         L.bfpq_int_quantize.argtypes = [vp, vp, i64, i64, i64, i32, i32, vp, vp]
@@ -97,8 +91,8 @@ def load_library():
         L.bfpq_hbfp_linear_decode.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
         L.bfpq_hbfp_linear_tiled_ok.argtypes = [i64, i64]
         L.bfpq_hbfp_linear_decode_tiled.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
-        for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_quantize_threshold_onepass", "bfpq_select_hist_prepare", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
-                     "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan", "bfpq_tie_count",
+        for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
+                     "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
                      "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize", "bfpq_hbfp_linear_slices",
                      "bfpq_hbfp_linear_decode", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled"):
             getattr(L, name).restype = i32
@@ -106,10 +100,10 @@ def load_library():
         return _lib
 
 
-EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_tie_workspace_elems", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_threshold_onepass", "bfpq_select_hist_prepare",
+EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_select_ws_bytes", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
-                    "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_scan",
-                    "bfpq_tie_count", "bfpq_threshold_apply", "bfpq_quantize_threshold")
+                    "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
+                    "bfpq_threshold_apply", "bfpq_quantize_threshold")
 
 
 def check(rc, what):
@@ -240,70 +234,62 @@ def quantize_nm(t, block_size, mant_bits, epsilon, N=0, M=0, sparsify_first=True
 
 
 class SelectWorkspace:
-    """Device scratch of the unstructured path (state + histogram + per-chunk tie counts)."""
+    """Device scratch of the unstructured path (include/bfpq.h: ws_dev): bfpq_select_state, the histogram buffers of the
+    single-device launches (cleared by the apply launch of the same call), and the tie bookkeeping.  One per (device, stream): the launches of
+    one call communicate through it."""
 
     def __init__(self, device):
         self.device = device
-        self.state = torch.zeros(SELECT_STATE_BYTES // 8, dtype=torch.int64, device=device)
-        self.hist = torch.zeros(SELECT_HIST_BINS, dtype=torch.int32, device=device)     # every scan re-zeroes it
-        self.tie = torch.zeros(1024, dtype=torch.int32, device=device)
+        nbytes = int(load_library().bfpq_select_ws_bytes())
+        self.ws = torch.zeros(nbytes // 8, dtype=torch.int64, device=device)
+        self.dirty = False                                 # a select whose histograms no apply launch has cleared yet
+        self.hist_ext = None                               # multi-GPU: the local histogram that gets all-gathered
 
-    def tie_ws(self, numel, dtype_code):
-        """one entry per 64-lane-item tile (tie prefix); grows with the largest tensor seen"""
-        need = int(load_library().bfpq_tie_workspace_elems(int(numel), int(dtype_code)))
-        if self.tie.numel() < need:
-            self.tie = torch.zeros(need, dtype=torch.int32, device=self.device)
-        return self.tie
+    def ext_hist(self):
+        if self.hist_ext is None:
+            self.hist_ext = torch.zeros(SELECT_HIST_COPIES * SELECT_HIST_ENTRIES, dtype=torch.int32, device=self.device)
+        return self.hist_ext
 
     def read_state(self):
         """host copy of bfpq_select_state (synchronises; for tests / diagnostics only)"""
-        raw = self.state.cpu().numpy().tobytes()
         import struct
-        prefix, mask, k_rem, tau, done, need, ties, k = struct.unpack_from("<IIqIIqqq", raw, 0)
-        return dict(prefix=prefix, prefix_mask=mask, k_rem=k_rem, tau=tau, done=done, need=need, ties=ties, k=k)
+        raw = self.ws[:SELECT_STATE_BYTES // 8].cpu().numpy().tobytes()
+        prefix, mask, k_rem, tau, done, need, ties, k, tie_base, flags = struct.unpack_from("<IIqIIqqqqI", raw, 0)
+        return dict(prefix=prefix, prefix_mask=mask, k_rem=k_rem, tau=tau, done=done, need=need, ties=ties, k=k,
+                    tie_base=tie_base, flags=flags)
 
 
-def select_threshold(t, k, ws, allreduce=None):
-    """radix-select the k-th smallest magnitude of t (device tensor); leaves the result in ws.state.
-    allreduce: optional callable(hist_tensor) that sums the histogram across ranks in place."""
+def select_threshold(t, k, ws, numel_global=None, allgather=None):
+    """radix-select the k-th smallest magnitude of t (device tensor) and leave threshold + tie bookkeeping in ws.
+    Multi-GPU: t is this rank's slab, k / numel_global are global, and allgather(hist) -> (hist_all [R, entries], R, rank)
+    gathers the per-rank histograms (the one exchange of the path; an empty slab still joins it)."""
     require_device_tensor(t)
     L = load_library()
     src = t.contiguous()
     code = DTYPE_CODE[src.dtype]
+    n = src.numel()
+    ng = n if numel_global is None else int(numel_global)
+    null = ctypes.c_void_p(0)
     with torch.cuda.device(src.device):
         st = _stream(src)
-        ws.prepared_for = None
-        for p in range(L.bfpq_select_passes(code)):       # ws.hist is zero on entry; every scan leaves it zeroed again
-            if p == 0 and allreduce is None and ONEPASS_UNSTRUCTURED:
-                # single device: the first histogram launch also zeroes the unit status words of the one-pass apply
-                tie = ws.tie_ws(src.numel(), code)
-                check(L.bfpq_select_hist_prepare(_ptr(src), src.numel(), code, p, _ptr(ws.state), _ptr(ws.hist), _ptr(tie), st),
-                      "bfpq_select_hist_prepare")
-                ws.prepared_for = (src.numel(), code)
-                if allreduce is not None:
-                    allreduce(ws.hist)
-                check(L.bfpq_select_scan(code, p, _ptr(ws.state), _ptr(ws.hist), int(k), st), "bfpq_select_scan")
+        if allgather is None and ws.dirty:                 # the previous select was never applied (diagnostic use)
+            check(L.bfpq_select_reset(_ptr(ws.ws), st), "bfpq_select_reset")
+        ws.dirty = allgather is None
+        for p in range(L.bfpq_select_passes(code)):
+            if allgather is None:
+                check(L.bfpq_select_hist(_ptr(src), n, code, p, int(k), ng, _ptr(ws.ws), null, st), "bfpq_select_hist")
+                check(L.bfpq_select_resolve(_ptr(src), n, code, p, int(k), null, 1, 0, _ptr(ws.ws), null, st), "bfpq_select_resolve")
                 continue
-            check(L.bfpq_select_hist(_ptr(src), src.numel(), code, p, _ptr(ws.state), _ptr(ws.hist), st), "bfpq_select_hist")
-            if allreduce is not None:
-                allreduce(ws.hist)
-            check(L.bfpq_select_scan(code, p, _ptr(ws.state), _ptr(ws.hist), int(k), st), "bfpq_select_scan")
-
-
-def _tie_ranks(src, code, ws, exchange_ties, st):
-    """tie counts per tile (skipped on the device when ranks are not needed) and, multi-GPU, the number
-    of ties held by lower ranks"""
-    L = load_library()
-    tie = ws.tie_ws(src.numel(), code)
-    check(L.bfpq_tie_count(_ptr(src), src.numel(), code, _ptr(ws.state), _ptr(tie), st), "bfpq_tie_count")
-    if exchange_ties is not None:
-        return exchange_ties(ws.state[6:7])              # bfpq_select_state.reserved[0]: this rank's tie total
-    return None
+            hist = ws.ext_hist()                           # zero on entry: resolve clears it again after the gather
+            check(L.bfpq_select_hist(_ptr(src) if n else null, n, code, p, int(k), ng, _ptr(ws.ws), _ptr(hist), st), "bfpq_select_hist")
+            hist_all, R, rank = allgather(hist)
+            check(L.bfpq_select_resolve(_ptr(src) if n else null, n, code, p, int(k), _ptr(hist_all), int(R), int(rank), _ptr(ws.ws),
+                                        _ptr(hist), st), "bfpq_select_resolve")
 
 
 def quantize_threshold(t, ws, block_size, mant_bits, epsilon, want_deq=True, code_bits=0, want_exp=False,
-                       stoch_seed=0, out=None, exchange_ties=None):
-    """S-first unstructured: prune with the threshold held in ws.state and HBFP-quantize, one pass
+                       stoch_seed=0, out=None):
+    """S-first unstructured: prune with the threshold held in ws and HBFP-quantize, one pass
     (bfpq_quantize_threshold).  Returns (deq | None, codes | None, exps | None) like quantize_nm."""
     require_device_tensor(t)
     L = load_library()
@@ -314,8 +300,6 @@ def quantize_threshold(t, ws, block_size, mant_bits, epsilon, want_deq=True, cod
     with torch.cuda.device(dev):
         st = _stream(src)
         fused = L.bfpq_is_fused(rows, cols, code, int(block_size), 0, 0)
-        onepass = bool(fused) and exchange_ties is None and ONEPASS_UNSTRUCTURED and src.data_ptr() % 16 == 0
-        tie_base = None if onepass else _tie_ranks(src, code, ws, exchange_ties, st)
         deq = (out if out is not None else torch.empty_like(src)) if want_deq else None
         codes = exps = None
         if code_bits:
@@ -323,42 +307,25 @@ def quantize_threshold(t, ws, block_size, mant_bits, epsilon, want_deq=True, cod
             codes = torch.empty(shape, dtype={4: torch.uint8, 8: torch.int8, 16: torch.int16}[code_bits], device=dev)
         if want_exp:
             exps = torch.empty((rows, (cols + block_size - 1) // block_size), dtype=torch.int8, device=dev)
-        if onepass and (deq is None or deq.data_ptr() % 16 == 0) and (codes is None or codes.data_ptr() % 16 == 0):
-            # single device, regular shape: no tie-count pass -- units in registers + decoupled look-back
-            tie = ws.tie_ws(src.numel(), code)
-            prepared = 1 if getattr(ws, "prepared_for", None) == (src.numel(), code) else 0
-            ws.prepared_for = None
-            check(L.bfpq_quantize_threshold_onepass(_ptr(src), _ptr(deq), _ptr(codes), _ptr(exps), rows, cols, code, int(block_size),
-                                                    int(mant_bits), float(epsilon), int(code_bits), int(stoch_seed),
-                                                    _ptr(exp_window_dev(src.dtype, dev)), _ptr(ws.state), _ptr(tie), prepared, st),
-                  "bfpq_quantize_threshold_onepass")
-            return deq, codes, exps
-        if onepass:                                            # (an unaligned output view: the multi-pass route after all)
-            tie_base = _tie_ranks(src, code, ws, exchange_ties, st)
         scratch = torch.empty_like(src) if (not fused and deq is None) else None
         check(L.bfpq_quantize_threshold(_ptr(src), _ptr(deq), _ptr(codes), _ptr(exps), rows, cols, code, int(block_size),
                                         int(mant_bits), float(epsilon), int(code_bits), int(stoch_seed),
-                                        _ptr(exp_window_dev(src.dtype, dev)), _ptr(ws.state), _ptr(ws.tie),
-                                        _ptr(tie_base), _ptr(scratch), st), "bfpq_quantize_threshold")
+                                        _ptr(exp_window_dev(src.dtype, dev)), _ptr(ws.ws), _ptr(scratch), st),
+              "bfpq_quantize_threshold")
+        ws.dirty = False
     return deq, codes, exps
 
 
-def threshold_apply(t, ws, out=None, tie_base=None, exchange_ties=None):
-    """zero everything below the threshold in ws.state plus the first `need` ties (flat order).
-    exchange_ties: optional callable(local_tie_total_tensor) -> int64 device tensor with the number of
-    ties held by lower ranks (multi-GPU)."""
+def threshold_apply(t, ws, out=None):
+    """zero everything below the threshold in ws plus the first `need` ties (flat order, lower ranks first)"""
     require_device_tensor(t)
     L = load_library()
     src = t.contiguous()
     code = DTYPE_CODE[src.dtype]
     with torch.cuda.device(src.device):
-        st = _stream(src)
         dst = out if out is not None else torch.empty_like(src)
-        tb = _tie_ranks(src, code, ws, exchange_ties, st)
-        if tb is not None:
-            tie_base = tb
-        check(L.bfpq_threshold_apply(_ptr(src), _ptr(dst), src.numel(), code, _ptr(ws.state), _ptr(ws.tie),
-                                     _ptr(tie_base), st), "bfpq_threshold_apply")
+        check(L.bfpq_threshold_apply(_ptr(src), _ptr(dst), src.numel(), code, _ptr(ws.ws), _stream(src)), "bfpq_threshold_apply")
+        ws.dirty = False
     return dst
 
 

@@ -10,14 +10,9 @@ import torch
 
 from . import native
 
-_ws = {}
-
-
 def _workspace(device):
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    if key not in _ws:
-        _ws[key] = native.SelectWorkspace(device)
-    return _ws[key]
+    from .bfp import bfp_ops
+    return bfp_ops._workspace(device)
 
 
 @torch.library.custom_op("bfpq::fake_quantize", mutates_args=())

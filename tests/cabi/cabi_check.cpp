@@ -73,18 +73,15 @@ int main()
     }
     // 3. unstructured: threshold / count equal to the oracle's, elements below the threshold zeroed
     {
-        void* d_state; uint32_t *d_hist, *d_tie;
-        HIP(hipMalloc(&d_state, BFPQ_SELECT_STATE_BYTES)); HIP(hipMalloc(&d_hist, 4 * BFPQ_SELECT_HIST_BINS));
-        const int64_t tw = bfpq_tie_workspace_elems(n, BFPQ_BF16);
-        HIP(hipMalloc(&d_tie, 4 * tw));
-        HIP(hipMemset(d_hist, 0, 4 * BFPQ_SELECT_HIST_BINS)); HIP(hipMemset(d_state, 0, BFPQ_SELECT_STATE_BYTES));
+        void* d_state;                                      // the select workspace begins with the bfpq_select_state
+        HIP(hipMalloc(&d_state, BFPQ_SELECT_WS_BYTES));
+        HIP(hipMemset(d_state, 0, BFPQ_SELECT_WS_BYTES));
         const int64_t k = (int64_t)((double)n * 0.5);
-        for (int p = 0; p < bfpq_select_passes(BFPQ_BF16); p++) {
-            RC(bfpq_select_hist(d_in, n, BFPQ_BF16, p, d_state, d_hist, s));
-            RC(bfpq_select_scan(BFPQ_BF16, p, d_state, d_hist, k, s));
+        for (int p = 0; p < bfpq_select_passes(BFPQ_BF16); p++) {       // single device: the workspace's own histogram buffers
+            RC(bfpq_select_hist(d_in, n, BFPQ_BF16, p, k, n, d_state, nullptr, s));
+            RC(bfpq_select_resolve(d_in, n, BFPQ_BF16, p, k, nullptr, 1, 0, d_state, nullptr, s));
         }
-        RC(bfpq_tie_count(d_in, n, BFPQ_BF16, d_state, d_tie, s));
-        RC(bfpq_threshold_apply(d_in, d_out, n, BFPQ_BF16, d_state, d_tie, nullptr, s));
+        RC(bfpq_threshold_apply(d_in, d_out, n, BFPQ_BF16, d_state, s));
         HIP(hipStreamSynchronize(s));
         bfpq_select_state st; HIP(hipMemcpy(&st, d_state, sizeof st, hipMemcpyDeviceToHost));
         HIP(hipMemcpy(h_out.data(), d_out, n * 2, hipMemcpyDeviceToHost));

@@ -26,8 +26,12 @@ def test_argument_validation_without_gpu():
     assert L.bfpq_quantize_nm(one, one, n, n, 4, 64, native.BF16, 64, 3, 1e-8, 0, 0, 1, 0, 0, n, one, n, n) == -1      # no exponent table
     assert L.bfpq_quantize_nm(one, one, n, n, 0, 64, native.BF16, 64, 3, 1e-8, 2, 4, 1, 0, 0, one, one, n, n) == 0     # empty tensor: ok, no launch
     assert L.bfpq_nm_sparsify(one, one, 4, 64, native.F32, 0, 4, one, n) == -1
-    assert L.bfpq_select_scan(native.BF16, 3, one, one, 5, n) == -1                                                     # pass out of range
-    assert L.bfpq_tie_workspace_elems(4096 * 11008, native.BF16) > 4096 * 11008 // 512
+    assert L.bfpq_select_resolve(one, 64, native.BF16, 3, 5, n, 1, 0, one, n, n) == -1                                  # pass out of range
+    assert L.bfpq_select_hist(one, 64, native.BF16, 0, 65, 64, one, n, n) == -1                                         # k > numel
+    assert L.bfpq_select_hist(one, 64, native.BF16, 0, 5, 1 << 33, one, n, n) == -2                                     # 32-bit counters
+    assert L.bfpq_select_resolve(one, 64, native.BF16, 0, 5, one, 2, 2, one, n, n) == -1                                # rank >= n_ranks
+    assert L.bfpq_select_ws_bytes() == 64 + 4 * (3 * 8 * 33024 + 2 * 256 + 4096 + 256 * 2048)
+    assert L.bfpq_threshold_apply(one, one, 0, native.BF16, one, n) == 0                                                # empty: no launch
     assert L.bfpq_int_quantize(one, one, 1, 4, 4, 5, 8, n, n) == -1
     assert L.bfpq_tune(0, 0) == -1 and L.bfpq_tune(99, 5) == -1 and L.bfpq_tune(0, 1280) == 0
     assert L.bfpq_is_fused(4, 64, 5, 64, 2, 4) == 0

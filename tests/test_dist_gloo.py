@@ -2,7 +2,7 @@
 The product has no CPU compute path, so the per-rank math is injected: the oracle for quantize / N:M, and a
 small numpy stand-in of the engine's select/apply protocol (same callbacks, same histogram layout) for the
 unstructured exchange.  What is under test is the distributed logic: slab ownership, ragged gathers, the
-histogram all-reduce, the tie-rank exchange, and "gathered == single-process"."""
+histogram all-gather (which also carries the tie counts of lower ranks), and "gathered == single-process"."""
 import os
 import socket
 import sys
@@ -25,7 +25,8 @@ def _free_port():
 
 
 class NumpyEngine:
-    """stand-in for native.select_threshold / threshold_apply on CPU bf16/fp16 tensors (one 15-bit radix pass)"""
+    """stand-in for native.select_threshold / threshold_apply on CPU bf16/fp16 tensors (one 15-bit radix pass; same
+    histogram layout and the same all-gather callback as the HIP engine)"""
 
     class WS:
         pass
@@ -39,26 +40,26 @@ class NumpyEngine:
         inf = 0x7F80 if t.dtype == torch.bfloat16 else 0x7C00
         return np.minimum(b, inf + 1)
 
-    def select_threshold(self, t, k, ws, allreduce=None):
-        hist = torch.from_numpy(np.bincount(self._keys(t), minlength=32768).astype(np.int32))
-        if allreduce is not None:
-            allreduce(hist)
-        c = np.cumsum(hist.numpy().astype(np.int64))
+    def select_threshold(self, t, k, ws, numel_global=None, allgather=None):
+        fine = np.bincount(self._keys(t), minlength=32768).astype(np.int32) if t.numel() else np.zeros(32768, np.int32)
+        local = torch.from_numpy(np.concatenate([fine, fine.reshape(256, 128).sum(1).astype(np.int32)]))   # fine + coarse bins
+        allh, R, rank = allgather(local) if allgather is not None else (local.view(1, -1), 1, 0)
+        allh = allh.numpy().astype(np.int64)[:, :32768]
+        hist = allh.sum(0)
+        c = np.cumsum(hist)
         if k == 0:
-            ws.tau, ws.need, ws.ties, ws.k = 0, 0, int(hist[0]), 0
+            ws.tau, ws.need, ws.ties, ws.k, ws.base = 0, 0, int(hist[0]), 0, 0
             return
         tau = int(np.searchsorted(c, k, side="left"))
         ws.tau, ws.k = tau, k
         ws.need = int(k - (c[tau - 1] if tau > 0 else 0))
         ws.ties = int(hist[tau])
+        ws.base = int(allh[:rank, tau].sum())              # ties held by lower ranks: read off the gathered histograms
 
-    def threshold_apply(self, t, ws, out=None, tie_base=None, exchange_ties=None):
+    def threshold_apply(self, t, ws, out=None):
         keys = self._keys(t)
         eq = keys == ws.tau
-        base = 0
-        if exchange_ties is not None:
-            base = int(exchange_ties(torch.tensor([int(eq.sum())], dtype=torch.int64)).item())
-        rank = base + np.cumsum(eq) - 1
+        rank = ws.base + np.cumsum(eq) - 1
         prune = (ws.k > 0) & ((keys < ws.tau) | (eq & (rank < ws.need)))
         flat = t.contiguous().view(-1).clone()
         flat[torch.from_numpy(prune)] = 0

@@ -35,7 +35,7 @@ def synth(rows, cols, dtype, scale=0.02, seed=1234):
 
 def test_native_library_is_the_one_running():
     assert torch.cuda.is_available()
-    assert pkg.load_library().bfpq_version() == 1
+    assert pkg.load_library().bfpq_version() == 2
     import os
     maps = open(f"/proc/{os.getpid()}/maps").read()
     assert "libbfpq.so" in maps
@@ -710,7 +710,7 @@ def test_packed_consumer_decode_linear(N, K, T, dname):
 def test_dist_paths_with_the_native_engine_on_rccl():
     """dist.py end to end on the device with the HIP engine and RCCL (backend "nccl"), one rank: the gloo tests cover the
     multi-rank protocol with a stand-in engine, this covers the real kernels, streams and collectives behind the same
-    functions -- sharded quantize (+ gather), the unstructured exchange (histogram all-reduce, tie all-gather), the
+    functions -- sharded quantize (+ gather), the unstructured exchange (histogram all-gather), the
     side-stream overlapped gather and the packed-bytes gather."""
     import torch.distributed as dist
     from quantization_sparsity_interplay_amd import dist as D
@@ -742,30 +742,109 @@ def test_dist_paths_with_the_native_engine_on_rccl():
         dist.destroy_process_group()
 
 
+def _flat_order_prune(xc, frac):
+    """the engine's own rule, restated in numpy: everything below the k-th smallest magnitude, plus the first `need`
+    elements EQUAL to it in flat index order (NaNs form one largest class, as in ATen's comparator)"""
+    dt = xc.dtype
+    if dt == torch.float32:
+        keys = xc.contiguous().view(torch.int32).numpy().reshape(-1).astype(np.int64) & 0x7FFFFFFF
+        inf = 0x7F800000
+    else:
+        keys = xc.contiguous().view(torch.int16).numpy().view(np.uint16).reshape(-1).astype(np.int64) & 0x7FFF
+        inf = 0x7F80 if dt == torch.bfloat16 else 0x7C00
+    keys = np.minimum(keys, inf + 1)
+    k = int(xc.numel() * frac)
+    out = xc.contiguous().view(-1).clone()
+    if k == 0:
+        return out.view(xc.shape)
+    tau = np.partition(keys, k - 1)[k - 1]
+    below = keys < tau
+    eq = keys == tau
+    need = k - int(below.sum())
+    rank = np.cumsum(eq) - 1
+    out[torch.from_numpy(below | (eq & (rank < need)))] = 0
+    return out.view(xc.shape)
+
+
 @pytest.mark.parametrize("dname", ["bf16", "f16", "f32"])
-def test_unstructured_onepass_equals_multipass(dname):
-    """single-device unstructured s->q: the one-pass kernel (units in registers/LDS + decoupled look-back for the flat-order
-    tie ranks) must give the bits of the multi-pass route (tie count + chunk sums + scan + apply) -- small and large tensors
-    (more units than workgroups: several rounds of look-back), tie-heavy inputs, every sparsity fraction.  The multi-pass
-    route itself is held to the oracle's contract by the cfg4 / G5 tests above."""
+def test_unstructured_exact_flat_order(dname):
+    """the three-launch unstructured path against the engine's tie rule restated on the host, bit for bit: small and large
+    tensors, ragged element counts (element loads), tie-heavy inputs (huge tie classes: the cut falls inside a segment and
+    a piece), every sparsity fraction, and the quantizer fused behind it."""
     dt = DT[dname]
-    shapes = [(4, 64), (64, 256), (257, 1024), (2048, 4096), (5120, 5120)]
-    default = native.ONEPASS_UNSTRUCTURED
-    try:
-        for rows, cols in shapes:
-            for tag in ("real", "coarse"):
-                xc = synth(rows, cols, dt, 1.0, seed=rows + cols)
-                if tag == "coarse":
-                    xc = (xc.float() * 4).round().div(4).to(dt)                     # ~20 distinct magnitudes: huge tie classes
-                x = xc.to(DEV)
-                for frac in ((0.5,) if rows > 1000 and tag == "real" else (0.1, 0.5, 0.9)):
+    shapes = [(4, 64), (64, 256), (257, 1024), (333, 777), (2048, 4096), (5120, 5120)]
+    for rows, cols in shapes:
+        for tag in ("real", "coarse"):
+            xc = synth(rows, cols, dt, 1.0, seed=rows + cols)
+            if tag == "coarse":
+                xc = (xc.float() * 4).round().div(4).to(dt)                     # ~20 distinct magnitudes
+            x = xc.to(DEV)
+            for frac in ((0.5,) if rows > 1000 and tag == "real" else (0.1, 0.5, 0.9)):
+                want = _flat_order_prune(xc, frac)
+                got = bfp_ops._unstructured_sparsity(x, 'cuda', frac)
+                assert_bits_equal(bits(got), bits(want), dt, f"prune [{rows},{cols}] {tag} frac={frac}")
+                if cols % 64 == 0:
                     c = cfg(w_sparsity=True, sparsity_mode='unstructured', sparsity_frac=frac, first='s')
-                    native.ONEPASS_UNSTRUCTURED = True
-                    a = bfp_ops.float_to_bfp_blocked(x, **c, identifier='w')
-                    err = int(bfp_ops._workspace(x.device).state[7].item())
-                    native.ONEPASS_UNSTRUCTURED = False
-                    b = bfp_ops.float_to_bfp_blocked(x, **c, identifier='w')
-                    assert err == 0, "a look-back spin hit its cap"
-                    assert_bits_equal(bits(a), bits(b), dt, f"one-pass vs multi-pass [{rows},{cols}] {tag} frac={frac}")
-    finally:
-        native.ONEPASS_UNSTRUCTURED = default
+                    q = bfp_ops.float_to_bfp_blocked(x, **c, identifier='w')
+                    assert_bits_equal(bits(q), bits(O.no_sparsity_float_to_bfp(want, 64, 3)), dt, f"prune+quantize [{rows},{cols}] {tag} frac={frac}")
+
+
+def test_unstructured_window_miss_falls_back_to_recount():
+    """A tensor whose segments live on wildly different scales: the per-segment histogram windows (2048 bins around the
+    segment's own quantile) do not cover the global threshold everywhere, so the resolve launch recounts those segments and
+    the apply launch ranks the whole cut segment -- slower, same bits.  Also all-zero and constant tensors."""
+    rows, cols = 2048, 4096
+    g = torch.Generator().manual_seed(7)
+    base = torch.randn(rows, cols, generator=g)
+    scale = torch.logspace(-30, 30, rows, base=2.0).view(rows, 1)               # 60 binades across the rows
+    for dt in (torch.bfloat16, torch.float16):
+        xc = (base * (scale if dt == torch.bfloat16 else scale.clamp(2.0 ** -12, 2.0 ** 12))).to(dt)
+        xc[100:140] = xc[5]                                                      # repeated rows: ties far apart in flat order
+        xc[::7, ::3] = 0
+        x = xc.to(DEV)
+        for frac in (0.3, 0.5, 0.77):
+            got = bfp_ops._unstructured_sparsity(x, 'cuda', frac)
+            assert_bits_equal(bits(got), bits(_flat_order_prune(xc, frac)), dt, f"heterogeneous rows {dt} frac={frac}")
+        ws = bfp_ops._workspace(x.device)
+        st = ws.read_state()
+        assert st["done"] == 1
+    for val in (0.0, 0.37):
+        xc = torch.full((512, 1024), val, dtype=torch.bfloat16)
+        got = bfp_ops._unstructured_sparsity(xc.to(DEV), 'cuda', 0.5)
+        assert_bits_equal(bits(got), bits(_flat_order_prune(xc, 0.5)), torch.bfloat16, f"constant {val}")
+
+
+@pytest.mark.parametrize("shape", [(13824, 5120), (5120, 13824)])
+def test_oracle_parity_cfg4_13b_mlp_shapes(shape):
+    """cfg 4 at the LLaMA-13B MLP shapes (gate/up [13824,5120], down [5120,13824]) bf16, HBFP4 + 50 % unstructured,
+    sparsify -> quantize: the oracle's contract (same threshold and count, identical outside the tie class; reference
+    bfp_ops.py:61-71) and the quantizer on the engine's own pruned tensor (reference :35-59)."""
+    xc = synth(shape[0], shape[1], torch.bfloat16)
+    x = xc.to(DEV)
+    ys = bfp_ops._unstructured_sparsity(x, 'cuda', 0.5)
+    _tie_class_check(xc, ys, 0.5, torch.bfloat16, f"cfg4 {shape} s")
+    assert int((ys == 0).sum()) == shape[0] * shape[1] // 2
+    c = cfg(w_sparsity=True, sparsity_mode='unstructured', first='s')
+    yq = bfp_ops.float_to_bfp_blocked(x, **c, identifier='w')
+    want = O.no_sparsity_float_to_bfp(ys.cpu(), 64, 3)
+    assert_bits_equal(bits(yq), bits(want), torch.bfloat16, f"cfg4 {shape} s then q")
+
+
+def test_unstructured_graph_replay_odd_call_count():
+    """the histogram buffers alternate on the device, so a captured graph holding an ODD number of calls replays correctly"""
+    xs = [synth(512, 1024, torch.bfloat16, seed=s).to(DEV) for s in (1, 2, 3)]
+    c = cfg(w_sparsity=True, sparsity_mode='unstructured', first='s')
+    want = [bfp_ops.float_to_bfp_blocked(x, **c, identifier='w').clone() for x in xs]
+    outs = None
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        bfp_ops.float_to_bfp_blocked(xs[0], **c, identifier='w')              # (creates this stream's workspace outside the capture)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            outs = [bfp_ops.float_to_bfp_blocked(x, **c, identifier='w') for x in xs]
+        for _ in range(3):
+            graph.replay()
+    torch.cuda.synchronize()
+    for o, w in zip(outs, want):
+        assert torch.equal(o, w)
