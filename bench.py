@@ -6,27 +6,33 @@
 A "step" is one pass of the hot path (reference float_to_bfp_blocked, bfp_ops.py:124-149) over one
 synthetic LLaMA-7B down_proj weight [4096, 11008] bf16: 2:4 magnitude pruning then HBFP4 (sign + 3
 mantissa bits, shared exponent per block of 64), drop-in mode (dequantised bf16 tensor out) -- the
-configuration BASELINE.json's metric is quoted on.  Steps rotate over `--rotate` distinct input/output
-buffer pairs (default 8 x 90 MB in + 8 x 90 MB out) so reads come from HBM, not from the 256 MB
-Infinity Cache.  The K timed launches are captured in one hipGraph (the per-launch host cost of the
-Python boundary is otherwise comparable to the ~40 us kernel); --eager times the plain call path.
+configuration BASELINE.json's metric is quoted on.
 
-Multi-GPU (launched by torch.distributed.run, one rank per GPU): rows are the sharding unit, every
-rank quantizes its own [4096, 11008] slab (weak scaling, no data-path collective);
---allgather additionally reassembles the packed result on every rank with an RCCL all-gather.
+N = 1: steps rotate over `--rotate` distinct input/output buffer pairs (default 8 x 90 MB in + 8 x 90 MB
+out) so reads come from HBM, not from the 256 MB Infinity Cache, and the K timed launches are captured in
+one hipGraph (--eager times the plain Python call path instead).
+
+N > 1 (one rank per GPU; `python bench.py --gpus N` starts torch.distributed.run itself when it was not
+launched by it): the north-star form -- ONE [4096, 11008] weight row-sharded over the N ranks (rank r owns
+rows [r*4096/N, (r+1)*4096/N)), every rank runs the same kernel on its slab and an RCCL all-gather
+reassembles the whole fake-quantised tensor on every rank: STRONG scaling, `value` = elements of the whole
+tensor / time of (kernel + all-gather).  The packed form of the gather (4-bit codes + int8 exponents,
+0.516 B/element on the wire instead of 2) is timed next to it and reported under "packed".  Before timing,
+rank 0 checks the gathered tensor bit for bit against an un-sharded run of the same kernel.
+--weak keeps the round-1 measurement: every rank its own [4096, 11008] slab, no collective.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 
@@ -43,10 +49,10 @@ def parse():
     ap.add_argument("--block", type=int, default=64)
     ap.add_argument("--nm", default="2:4", help="N:M, or 0:0 for dense")
     ap.add_argument("--first", default="s", choices=["s", "q"])
-    ap.add_argument("--mode", default="dropin", choices=["dropin", "packed", "both"])
+    ap.add_argument("--mode", default="dropin", choices=["dropin", "packed", "both"], help="N = 1 / --weak: which outputs the kernel writes")
     ap.add_argument("--rotate", type=int, default=8)
     ap.add_argument("--eager", action="store_true")
-    ap.add_argument("--allgather", action="store_true")
+    ap.add_argument("--weak", action="store_true", help="N > 1: every rank its own [rows, cols] slab, no collective")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real multi-GPU; gloo only to rehearse N>1 on one GPU")
@@ -54,44 +60,82 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, dtype, N, M, cfg_kwargs):
-    """the CPU oracle (a C/OpenMP port of the reference algorithm, oracle/bfp_oracle.c) timed on this
-    box's host cores on the same workload; baseline only."""
-    from oracle import oracle as O
-    threads = os.cpu_count() or 1
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU as a CHILD process (nothing in this
+    process has touched the GPU yet) and pass its output through"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def cpu_threads():
+    n = os.cpu_count() or 1
     try:
-        threads = len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    threads = min(threads, int(os.environ.get("BFPQ_CPU_THREADS", "16")))   # a 1-GPU box's CPU share is 16 cores
+    return min(n, int(os.environ.get("BFPQ_CPU_THREADS", "16")))   # a 1-GPU box's CPU share is 16 cores
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, dtype, cfg_kwargs):
+    """The reference's own CPU path does not travel to the GPU box; what is timed beside the GPU number is
+    (a) oracle/torch_restatement.py -- the same ATen op sequence as bfp_ops.py:29-149, pinned bit for bit to the
+        reference's fixtures (tests/test_oracle_golden.py) -- i.e. what the reference's pure-PyTorch path costs here, and
+    (b) oracle/bfp_oracle.c, the C + OpenMP port (the faster, conservative comparison).  Baselines only."""
+    import torch
+    from oracle import oracle as O
+    from oracle import torch_restatement as R
+    threads = cpu_threads()
     os.environ["OMP_NUM_THREADS"] = str(threads)
+    torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(1234)
     w = (torch.randn(args.rows, args.cols, generator=g) * 0.02).to(dtype)
-    O.float_to_bfp_blocked(w[:64], **cfg_kwargs, identifier='w')          # build + warm
-    t_end = time.perf_counter() + args.cpu_seconds
-    n = 0
-    t0 = time.perf_counter()
-    while True:
-        O.float_to_bfp_blocked(w, **cfg_kwargs, identifier='w')
-        n += 1
-        if time.perf_counter() >= t_end or n >= 50:
-            break
-    dt = time.perf_counter() - t0
+
+    def timed(fn, budget):
+        fn(w[:64])                                                 # build + warm
+        n, t0 = 0, time.perf_counter()
+        while True:
+            fn(w)
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= budget or n >= 50:
+                return n, dt
+
+    n, dt = timed(lambda x: R.fake_quantize(x, **cfg_kwargs, identifier='w'), args.cpu_seconds * 0.6)
+    n2, dt2 = timed(lambda x: O.float_to_bfp_blocked(x, **cfg_kwargs, identifier='w'), args.cpu_seconds * 0.4)
+    what = f"[{args.rows},{args.cols}] {args.dtype}"
     return {"value": w.numel() * n / dt, "unit": "elems/s", "cores": threads, "kind": "port",
-            "sample": f"{n} full passes over the same [{args.rows},{args.cols}] {args.dtype} workload, "
-                      f"oracle/bfp_oracle.c (C + OpenMP, {threads} threads), {dt:.1f} s"}
+            "port_of": "pure-torch op-for-op restatement of bfp_ops.py:29-149 (oracle/torch_restatement.py: abs/max/log2/ceil/pow/"
+                       "div/round/mul/min/max, topk/full/scatter_/where), bit-identical to the reference's fixtures",
+            "cpu_model": cpu_model(), "torch_threads": threads,
+            "sample": f"{n} full passes over the same {what} workload in {dt:.1f} s",
+            "c_port": {"value": w.numel() * n2 / dt2, "unit": "elems/s", "cores": threads,
+                       "sample": f"{n2} full passes, oracle/bfp_oracle.c (C + OpenMP, {threads} threads), {dt2:.1f} s"}}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the engine has no CPU path)")
     if args.one_device:
@@ -111,35 +155,11 @@ def main():
 
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     N, M = (int(v) for v in args.nm.split(":"))
+    N, M = (N, M) if N < M else (0, 0)
     esize = 4 if dtype == torch.float32 else 2
-    numel = args.rows * args.cols
-    want_deq = args.mode in ("dropin", "both")
-    code_bits = 0 if args.mode == "dropin" else (4 if args.mant_bits <= 3 else 8 if args.mant_bits <= 7 else 16)
-    want_exp = args.mode != "dropin"
-
-    # synthetic inputs: seed 1234 (+ buffer index, + rank), randn * 0.02, generated on CPU then copied
+    strong = world > 1 and not args.weak
+    pack_bits = 4 if args.mant_bits <= 3 else 8 if args.mant_bits <= 7 else 16
     R = max(1, args.rotate)
-    ins, outs = [], []
-    for r in range(R):
-        g = torch.Generator().manual_seed(1234 + r + 1000 * rank)
-        ins.append((torch.randn(args.rows, args.cols, generator=g) * 0.02).to(dtype).to(dev))
-        outs.append(torch.empty(args.rows, args.cols, dtype=dtype, device=dev) if want_deq else None)
-
-    gather_buf = None
-    if args.allgather and world > 1:
-        gather_buf = torch.empty(world * args.rows, args.cols, dtype=dtype, device=dev)
-
-    def step(i):
-        r = i % R
-        res = native.quantize_nm(ins[r], args.block, args.mant_bits, 1e-8, N=N if N < M else 0, M=M if N < M else 0,
-                                 sparsify_first=(args.first == "s"), want_deq=want_deq, code_bits=code_bits,
-                                 want_exp=want_exp, out=outs[r])
-        if gather_buf is not None:
-            dist.all_gather_into_tensor(gather_buf, res[0])
-        return res
-
-    if not pkg.load_library().bfpq_is_fused(args.rows, args.cols, native.DTYPE_CODE[dtype], args.block, N, M):
-        print("note: this shape takes the general (multi-launch) path", file=sys.stderr)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -147,59 +167,168 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    sync_all()
+    def quantize(x, out=None, packed=False, codes_out=None, exps_out=None):
+        return native.quantize_nm(x, args.block, args.mant_bits, 1e-8, N=N, M=M, sparsify_first=(args.first == "s"),
+                                  want_deq=not packed, code_bits=pack_bits if packed else 0, want_exp=packed,
+                                  out=out, codes_out=codes_out, exps_out=exps_out)
 
-    use_graph = not args.eager and gather_buf is None and args.mode == "dropin"
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if use_graph:
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            for i in range(args.steps):
-                step(i)
-        graph.replay()                                              # untimed: upload + first replay
+    def timed_loop(fn, steps, warmup, graph):
+        """(wall seconds, HIP-event milliseconds) of `steps` calls of fn(i), barrier + synchronize on both sides"""
+        for i in range(warmup):
+            fn(i)
         sync_all()
-        t0 = time.perf_counter()
-        ev0.record()
-        graph.replay()
-        ev1.record()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if graph:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for i in range(steps):
+                    fn(i)
+            g.replay()                                              # untimed: upload + first replay
+            sync_all()
+            t0 = time.perf_counter()
+            ev0.record()
+            g.replay()
+            ev1.record()
+        else:
+            t0 = time.perf_counter()
+            ev0.record()
+            for i in range(steps):
+                fn(i)
+            ev1.record()
         sync_all()
-        t1 = time.perf_counter()
-    else:
-        sync_all()
-        t0 = time.perf_counter()
-        ev0.record()
-        for i in range(args.steps):
-            step(i)
-        ev1.record()
-        sync_all()
-        t1 = time.perf_counter()
+        return time.perf_counter() - t0, ev0.elapsed_time(ev1)
 
-    wall = t1 - t0
-    ev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+        return float(t.item())
+
+    def all_ranks(x):
+        if world == 1:
+            return [x]
+        t = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        out = torch.empty(world, dtype=torch.float64, device=t.device)
+        dist.all_gather_into_tensor(out, t)
+        return [float(v) for v in out.cpu()]
+
+    extra = {}
+    if not strong:
+        # ---- one rank = one whole [rows, cols] tensor (N = 1: the headline; --weak: N independent slabs) -----------
+        want_deq = args.mode in ("dropin", "both")
+        code_bits = 0 if args.mode == "dropin" else pack_bits
+        want_exp = args.mode != "dropin"
+        numel = args.rows * args.cols
+        ins, outs = [], []
+        for r in range(R):
+            g = torch.Generator().manual_seed(1234 + r + 1000 * rank)
+            ins.append((torch.randn(args.rows, args.cols, generator=g) * 0.02).to(dtype).to(dev))
+            outs.append(torch.empty(args.rows, args.cols, dtype=dtype, device=dev) if want_deq else None)
+
+        def step(i):
+            r = i % R
+            return native.quantize_nm(ins[r], args.block, args.mant_bits, 1e-8, N=N, M=M, sparsify_first=(args.first == "s"),
+                                      want_deq=want_deq, code_bits=code_bits, want_exp=want_exp, out=outs[r])
+
+        use_graph = not args.eager and args.mode == "dropin"
+        wall, ev_ms = timed_loop(step, args.steps, args.warmup, use_graph)
+        wall = max_over_ranks(wall)
+        value = world * numel * args.steps / wall
+        kern_us = ev_ms * 1e3 / args.steps
+        bytes_per_launch = numel * esize + (numel * esize if want_deq else 0) + (numel * code_bits // 8 if code_bits else 0) + \
+            (numel // args.block if (want_exp and args.block) else 0)
+        parallelism = f"row-sharded x{world}, no collective (weak scaling)" if world > 1 else "1 GPU"
+        launch = "hipGraph" if use_graph else "eager"
+        output = args.mode
+        rows_per_gpu = args.rows
+    else:
+        # ---- north-star form: ONE [rows, cols] weight, row-sharded, RCCL all-gather of the result -------------------
+        from quantization_sparsity_interplay_amd import dist as qd
+        chk = torch.tensor([float(rank + 1)], device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(chk)                                        # did the collective library see `world` ranks?
+        extra["rccl_ranks"] = world if abs(float(chk.item()) - world * (world + 1) / 2) < 1e-6 else -1
+        extra["collective_backend"] = "RCCL (torch.distributed 'nccl')" if args.backend == "nccl" else args.backend
+        if args.rows % world:
+            raise SystemExit(f"--rows {args.rows} must divide by the number of ranks ({world}) in the strong-scaling mode")
+        lo, hi = qd.row_range(args.rows, world, rank)
+        per = hi - lo
+        numel = args.rows * args.cols
+        fulls = []
+        for r in range(R):
+            g = torch.Generator().manual_seed(1234 + r)
+            fulls.append((torch.randn(args.rows, args.cols, generator=g) * 0.02).to(dtype))     # same bits as the 1-GPU run
+        ins = [f[lo:hi].to(dev) for f in fulls]
+        slabs = [torch.empty(per, args.cols, dtype=dtype, device=dev) for _ in range(R)]
+        wholes = [torch.empty(args.rows, args.cols, dtype=dtype, device=dev) for _ in range(R)]
+        nblk = (args.cols + args.block - 1) // args.block
+        ccols = (args.cols + 1) // 2 if pack_bits == 4 else args.cols
+        cdt = {4: torch.uint8, 8: torch.int8, 16: torch.int16}[pack_bits]
+        pc = [torch.empty(per, ccols, dtype=cdt, device=dev) for _ in range(2)]
+        pe = [torch.empty(per, nblk, dtype=torch.int8, device=dev) for _ in range(2)]
+        wc = [torch.empty(args.rows, ccols, dtype=cdt, device=dev) for _ in range(2)]
+        we = [torch.empty(args.rows, nblk, dtype=torch.int8, device=dev) for _ in range(2)]
+
+        def kernel_only(i):
+            quantize(ins[i % R], out=slabs[i % R])
+
+        def gather_only(i):
+            qd.all_gather_into(wholes[i % R], slabs[i % R])
+
+        def step(i):
+            kernel_only(i)
+            gather_only(i)
+
+        def packed_step(i):
+            quantize(ins[i % R], packed=True, codes_out=pc[i % 2], exps_out=pe[i % 2])
+            qd.all_gather_into(wc[i % 2], pc[i % 2])
+            qd.all_gather_into(we[i % 2], pe[i % 2])
+
+        def packed_gather_only(i):
+            qd.all_gather_into(wc[i % 2], pc[i % 2])
+            qd.all_gather_into(we[i % 2], pe[i % 2])
+
+        # parity of the sharded form: gathered == un-sharded, bit for bit (rank 0 has the whole input)
+        step(0)
+        packed_step(0)
+        torch.cuda.synchronize()
+        if rank == 0:
+            ref = quantize(fulls[0].to(dev))[0]
+            _, rc, re = quantize(fulls[0].to(dev), packed=True)
+            extra["gathered_equals_single_gpu"] = bool(torch.equal(wholes[0].view(torch.int16 if esize == 2 else torch.int32),
+                                                                   ref.view(torch.int16 if esize == 2 else torch.int32)))
+            extra["gathered_packed_equals_single_gpu"] = bool(torch.equal(wc[0], rc) and torch.equal(we[0], re))
+            del ref, rc, re
+
+        short = max(20, args.steps // 4)
+        _, k_ms = timed_loop(kernel_only, short, 5, False)
+        _, c_ms = timed_loop(gather_only, short, 5, False)
+        _, pcoll_ms = timed_loop(packed_gather_only, short, 5, False)
+        pwall, _ = timed_loop(packed_step, short, 5, False)
+        pwall = max_over_ranks(pwall)
+        wall, ev_ms = timed_loop(step, args.steps, args.warmup, False)
+        wall = max_over_ranks(wall)
+        value = numel * args.steps / wall
+        kern_us = k_ms * 1e3 / short
+        extra["per_rank_kernel_us"] = all_ranks(kern_us)
+        extra["per_rank_collective_us"] = all_ranks(c_ms * 1e3 / short)
+        extra["packed"] = {"value": numel * short / pwall, "unit": "elems/s", "ms_per_step": pwall * 1e3 / short,
+                           "wire_bytes_per_rank": per * (ccols * (1 if pack_bits <= 8 else 2) + nblk),
+                           "per_rank_collective_us": all_ranks(pcoll_ms * 1e3 / short),
+                           "what": f"kernel writes {pack_bits}-bit codes + int8 exponents, two all-gathers reassemble them"}
+        extra["wire_bytes_per_rank"] = per * args.cols * esize
+        bytes_per_launch = 2 * per * args.cols * esize                # the slab kernel: read once, write once
+        parallelism = f"one [{args.rows},{args.cols}] weight row-sharded x{world} + RCCL all-gather of the {args.dtype} result (strong scaling)"
+        launch = "eager (kernel + collective per step)"
+        output = "dropin, gathered whole on every rank"
+        rows_per_gpu = per
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
-        value = world * numel * args.steps / wall
-        # algorithmic bytes per launch: read the tensor once, write each requested output once
-        nblk = numel // args.block if args.block else 0
-        bytes_per_launch = numel * esize
-        if want_deq:
-            bytes_per_launch += numel * esize
-        if code_bits:
-            bytes_per_launch += numel * code_bits // 8
-        if want_exp:
-            bytes_per_launch += nblk
-        kern_us = ev_ms * 1e3 / args.steps
         achieved = bytes_per_launch / (kern_us * 1e-6) / 1e9
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and not strong:
             try:
                 tj = json.load(open(tpath))
                 key = f"{args.rows}x{args.cols}_{args.dtype}_m{args.mant_bits}_b{args.block}_{args.nm}_{args.first}_{args.mode}"
@@ -207,28 +336,28 @@ def main():
                     traffic, traffic_src = tj[key]["hbm_bytes_per_launch"], tj[key].get("source")
             except Exception:
                 pass
-        cfg_kwargs = pkg.BFPConfig.hbfp(args.mant_bits + 1, args.block, w_sparsity=(N < M and M > 0), N=N, M=M,
+        cfg_kwargs = pkg.BFPConfig.hbfp(args.mant_bits + 1, args.block, w_sparsity=M > 0, N=N, M=M,
                                         sparsity_mode='structured', first=args.first).to_kwargs()
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args, dtype, N, M, cfg_kwargs)
+            cpu = cpu_baseline(args, dtype, cfg_kwargs)
         line = {
             "metric": "weight elems/sec quantized+sparsified (BFP-int4, 2:4) on 4096x11008; % HBM roofline",
             "value": value, "unit": "elems/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"LLaMA-7B down_proj weight [{args.rows},{args.cols}] {args.dtype} -> "
                                    f"{args.nm} magnitude pruning ({'sparsify->quantize' if args.first == 's' else 'quantize->sparsify'}) "
                                    f"+ HBFP{args.mant_bits + 1} (mant_bits={args.mant_bits}, block={args.block}), round-half-even",
-                       "output": args.mode, "rows_per_gpu": args.rows, "cols": args.cols,
-                       "parallelism": f"row-sharded x{world}" + (" + RCCL all-gather" if gather_buf is not None else ""),
-                       "launch": "hipGraph" if use_graph else "eager", "rotating_buffers": R},
+                       "output": output, "rows_per_gpu": rows_per_gpu, "cols": args.cols,
+                       "parallelism": parallelism, "launch": launch, "rotating_buffers": R},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "kernel": "k_fused_flat",
                          "avg_launch_us": kern_us, "traffic_source": traffic_src},
             "cpu_baseline": cpu,
         }
+        line.update(extra)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

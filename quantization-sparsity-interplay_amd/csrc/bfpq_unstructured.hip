@@ -83,37 +83,27 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
     STAMP(0, 1);
     __syncthreads();
     STAMP(0, 2);
-    // flush of the non-zero bins by integer atomics (deterministic) into this workgroup's COPY of the histogram: with
-    // all workgroups adding into one copy every hot address takes 256 serialised adds (~3 us behind the streaming loop)
     hist += (size_t)(blockIdx.x % BFPQ_SELECT_HIST_COPIES) * BFPQ_SELECT_HIST_ENTRIES;
-    for (int i = t; i < nbins; i += kSelThreads) {
-        const uint32_t c = s_hist[i];
-        if (c) atomicAdd(&hist[i], c);
-    }
-    STAMP(0, 3);
-    if (!last && nbits != 15) return;
-    if (nbits != 15) {                                      // fp32, last digit (512 bins): the whole private histogram
-        for (int i = t; i < nbins; i += kSelThreads) ws->windows[blockIdx.x][i] = s_hist[i];
-        if (t == 0) ws->seg_win[blockIdx.x] = 0u;
-        return;
-    }
-    // coarse histogram (256 bins of 128): four threads per coarse bin, each sums 32 bins in a rotated order (bank = 4 x
-    // ((j + q) mod 8) + r: two lanes per bank), then a quad reduction
-    {
+    const bool windows = last && nbits == 15;
+    if (nbits == 15) {
+        // coarse histogram (256 bins of 128): four threads per coarse bin, each sums 32 bins with 16-byte LDS reads in a
+        // rotated order (two lanes per bank), then a quad reduction
         const int q = t >> 2, r = t & 3;
         uint32_t sum = 0;
-#pragma unroll 8
-        for (int j = 0; j < 32; j++) sum += s_hist[q * 128 + ((j + q) & 31) * 4 + r];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint4 c4 = *reinterpret_cast<const uint4*>(&s_hist[q * 128 + ((j + q) & 7) * 16 + r * 4]);
+            sum += c4.x + c4.y + c4.z + c4.w;
+        }
         sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
         sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
         if (r == 0) { s_coarse[q] = sum; if (sum) atomicAdd(&hist[kFineBins + q], sum); }
+        __syncthreads();
     }
-    STAMP(0, 4);
-    if (!last) return;
-    __syncthreads();
+    STAMP(0, 3);
     // window: the 16 coarse bins (2048 bins) around the one that holds the segment's own k-quantile.  The first wave
-    // finds it: four coarse sums per lane, one wave scan.
-    if (t < 64) {
+    // finds it (four coarse sums per lane, one wave scan) while the others already flush.
+    if (windows && t < 64) {
         const uint4 c4 = *reinterpret_cast<const uint4*>(&s_coarse[t * 4]);
         const uint32_t mine = c4.x + c4.y + c4.z + c4.w;
         const uint32_t incl = wave_incl_scan(mine);
@@ -133,6 +123,28 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
             s_res[0] = (uint32_t)clo * 128u;
             ws->seg_win[blockIdx.x] = ((uint32_t)clo * 128u) | (inside != seg_elems ? 0x80000000u : 0u);
         }
+    }
+    // flush of the non-zero bins by integer atomics (deterministic) into this workgroup's COPY of the histogram: with
+    // all workgroups adding into one copy every hot address takes 256 serialised adds (~3 us behind the streaming loop).
+    // The LDS reads of a thread are issued together.
+    if (nbits == 15) {
+        uint32_t c[32];
+#pragma unroll
+        for (int j = 0; j < 32; j++) c[j] = s_hist[t + j * kSelThreads];
+#pragma unroll
+        for (int j = 0; j < 32; j++) if (c[j]) atomicAdd(&hist[t + j * kSelThreads], c[j]);
+    } else {
+        for (int i = t; i < nbins; i += kSelThreads) {
+            const uint32_t c = s_hist[i];
+            if (c) atomicAdd(&hist[i], c);
+        }
+    }
+    STAMP(0, 4);
+    if (!last) return;
+    if (nbits != 15) {                                      // fp32, last digit (512 bins): the whole private histogram
+        for (int i = t; i < nbins; i += kSelThreads) ws->windows[blockIdx.x][i] = s_hist[i];
+        if (t == 0) ws->seg_win[blockIdx.x] = 0u;
+        return;
     }
     __syncthreads();
     const int lo = (int)s_res[0];

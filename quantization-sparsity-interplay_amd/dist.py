@@ -32,19 +32,30 @@ def shard_rows(t, world_size, rank):
     return t[lo:hi]
 
 
+def all_gather_into(out, inp, group=None):
+    """dist.all_gather_into_tensor; with the `gloo` backend (CPU rehearsal of the multi-rank paths, also with several
+    ranks on ONE device) device tensors are staged through host memory, since gloo moves host bytes"""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host.view(-1), inp.contiguous().view(-1).cpu(), group=group)
+        out.copy_(host)
+        return
+    dist.all_gather_into_tensor(out, inp, group=group)
+
+
 def all_gather_rows(local, rows_total, group=None):
     """reassemble a row-sharded tensor on every rank (plain concatenation along dim 0)"""
     world = dist.get_world_size(group)
     per = (rows_total + world - 1) // world
     if per * world == rows_total and local.shape[0] == per:
         out = torch.empty((rows_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        all_gather_into(out, local.contiguous(), group)
         return out
     # ragged: pad every slab to `per` rows, gather, cut
     pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     out = torch.empty((per * world,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
+    all_gather_into(out, pad, group)
     return out[:rows_total]
 
 
@@ -55,7 +66,7 @@ def _hist_allgather(group):
     def fn(hist):
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         allh = torch.empty(world * hist.numel(), dtype=hist.dtype, device=hist.device)
-        dist.all_gather_into_tensor(allh, hist.contiguous().view(-1), group=group)
+        all_gather_into(allh, hist.contiguous().view(-1), group)
         return allh.view(world, hist.numel()), world, rank
     return fn
 

@@ -189,3 +189,35 @@ def test_g9_int_format():
                         c = cfg(sparsity_num_format='int', mant_bits=8, block_size=32, first=first, sparsity_mode=mode, **{flag: True}, **extra)
                         y = O.float_to_bfp_blocked(x, **c, identifier=ident)
                         assert_bits_equal(bits(y), g[f"comp_{name}_{dname}_{first}_{mode[:1]}"], torch.float32, f"int comp {name} {dname} {first} {mode}")
+
+
+# ---- the pure-torch restatement that bench.py times as the CPU baseline (oracle/torch_restatement.py) ----------
+def test_torch_restatement_matches_reference_fixtures():
+    """op-for-op ATen restatement of bfp_ops.py:29-149 == the reference's own outputs (G2 quantize, G3 N:M incl. the
+    tie-heavy sets, G4 composed pipelines incl. unstructured tie positions), bit for bit"""
+    from oracle import torch_restatement as R
+    g = load("g2_quantize.npz")
+    for sname in ("s0.02", "s1", "s30"):
+        for dname, dt in DT.items():
+            x = from_bits(g[f"in_{sname}_{dname}"], dt)
+            for blk in (16, 32, 64):
+                for m in (3, 5, 7, 15):
+                    assert_bits_equal(bits(R.hbfp(x, blk, m, 1e-8)), g[f"out_{sname}_{dname}_b{blk}_m{m}"], dt, f"{sname} {dname} b{blk} m{m}")
+    g = load("g3_nm.npz")
+    rows = torch.from_numpy(g["m4_rows"].astype(np.float32) + 1.0)
+    for N in (1, 2, 3):
+        assert np.array_equal((R.prune_groups(rows, N, 4) != 0).numpy().astype(np.uint8), g[f"m4_keep_N{N}"]), N
+    for (N, M) in ((2, 8), (4, 8), (4, 16), (16, 32), (3, 6), (2, 5)):
+        r = g[f"rows_{N}_{M}"].astype(np.float32) + 1.0
+        sign = np.where(g[f"sign_{N}_{M}"] != 0, -1.0, 1.0).astype(np.float32)
+        keep = np.packbits((R.prune_groups(torch.from_numpy(r * sign), N, M) != 0).numpy().astype(np.uint8), axis=1)
+        assert np.array_equal(keep, g[f"keep_{N}_{M}"]), (N, M)
+    g = load("g4_composed.npz")
+    for dname, dt in DT.items():
+        x = from_bits(g[f"in_{dname}"], dt)
+        for first in ('s', 'q'):
+            for mode, extra in (("structured", dict(N=2, M=4)), ("structured", dict(N=4, M=8)), ("unstructured", dict(sparsity_frac=0.5))):
+                for m, blk in ((3, 64), (7, 16)):
+                    c = cfg(mant_bits=m, block_size=blk, first=first, sparsity_mode=mode, w_sparsity=True, **extra)
+                    tag = f"{dname}_{first}_{mode[:1]}_{extra.get('N', 0)}_{extra.get('M', 0)}_{extra.get('sparsity_frac', 0)}_m{m}_b{blk}"
+                    assert_bits_equal(bits(R.fake_quantize(x, **c, identifier='w')), g[f"out_{tag}"], dt, tag)
