@@ -113,7 +113,7 @@ __device__ __forceinline__ BlockScale block_scale(uint32_t max_key, int mant_bit
     int k = (int)(sb >> 23) - 127;
     uint32_t mant = sb & 0x7fffffu;
     if ((sb >> 23) == 0u) {                                          // fp32 subnormal (only with epsilon == 0)
-        const int lz = __clz((int)mant) - 8;                         // leading zeros inside the 23-bit field
+        const int lz = __clz((int)mant) - 9;                         // leading zeros inside the 23-bit field (bits 22..0)
         mant = (mant << (lz + 1)) & 0x7fffffu;
         k = -127 - lz;
     }

@@ -120,6 +120,8 @@ struct FusedArgs {
     int N;
     int code_bits;
     int force_slow;           // mant_bits wider than the dtype significand: always emulate step by step
+    int kb_lo, kb_span;       // hot16 path: dtype exponent fields of the block max it takes (kb_span < 0: never)
+    uint32_t maxv_c;          //   (2^m - 1) * 2^(e - m) in dtype bits = (fp32-biased e << MBITS) + maxv_c
     SelWs* selws;             // NM == -1 (global magnitude threshold): the select workspace (threshold + tie bookkeeping)
 };
 

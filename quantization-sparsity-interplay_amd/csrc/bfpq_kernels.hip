@@ -34,6 +34,16 @@ using namespace bfpq_dev;
 
 namespace {
 
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t bfi_b32(uint32_t mask, uint32_t a, uint32_t b) { uint32_t d; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b)); return d; }
+template <bool HI> __device__ __forceinline__ float fma_mix_f16(uint32_t a, float c)
+{
+    float d;                                                 // src0: the low / high half of a as fp16; src1 = 1.0, src2 = c in fp32
+    if constexpr (HI) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(c));
+    return d;
+}
+
 // scale of a block on the branch-free path; ok == false -> the caller emulates step by step instead
 struct FastScale { float inv, interval, qmax; int e; bool ok; };
 
@@ -62,6 +72,33 @@ __device__ __forceinline__ FastScale fast_scale(uint32_t max_key, int mant_bits,
     f.qmax = (float)((1u << mant_bits) - 1u);
     f.e = eb - 127;
     return f;
+}
+
+// The lean form of the same scale for 16-bit dtypes in drop-in mode ("hot16"), valid when the block max lies in the
+// range [kb_lo, kb_lo + kb_span] of dtype exponent fields that the host derived (FusedArgs): there max + epsilon rounds
+// back to max (epsilon below half an ulp), the interval and the magic constant below are normal numbers and nothing
+// overflows, so the shared exponent is just "exponent field of the max, plus one if its mantissa field is above the window".
+// Rounding then needs no division and no integer code at all:
+//     out = sign(x) * ((min(|x|, max_v) + C) - C),   C = 1.5 * 2^23 * interval
+// The sum is a multiple of ulp(C) = interval, rounded half-to-even by the adder -- the reference's round(x / interval)
+// * interval -- and clamping the magnitude first equals clamping the rounded value (max_v is on the grid).  The clamp is a
+// packed 16-bit integer min on the magnitude bits, the sign comes back with one bit-field insert per two elements.
+struct Hot16 { uint32_t maxv2; float C; bool ok; };
+
+template <int DT>
+__device__ __forceinline__ Hot16 hot16_scale(uint32_t max_key, const FusedArgs& a, const uint8_t* s_win)
+{
+    using T = Traits<DT>;
+    constexpr uint32_t EOFF = DT == BFPQ_F16 ? 112u : 0u;                 // dtype exponent field -> fp32 exponent field
+    Hot16 h;
+    const uint32_t kb = max_key >> T::MBITS, mant = max_key & ((1u << T::MBITS) - 1u);
+    const uint32_t win = s_win[kb + 33u + EOFF];                          // (kb <= 255: inside the 512-byte LDS copy)
+    const uint32_t eb = kb + EOFF + (mant > win ? 1u : 0u);               // fp32-biased shared exponent
+    h.ok = (kb - (uint32_t)a.kb_lo) <= (uint32_t)a.kb_span;
+    h.C = u2f(((eb - (uint32_t)a.mant_bits) << 23) + 0x0BC00000u);       // 1.5 * 2^(23 + e - m)
+    const uint32_t maxv = (eb << T::MBITS) + a.maxv_c;                    // (2^m - 1) * 2^(e - m) in dtype bits
+    h.maxv2 = maxv | (maxv << 16);
+    return h;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -297,64 +334,96 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
                 mx = m01 > m23 ? m01 : m23;
             }
             mx = group_max<LPBT>(mx, a.lpb);
-            const FastScale fs = fast_scale<DT>(mx, a.mant_bits, a.eps_dt, s_win);
-            e_blk = fs.e;
-            uint32_t raw[VEC];
-            if constexpr (VEC == 4) { raw[0] = d0; raw[1] = d1; raw[2] = d2; raw[3] = d3; }
-            else {
-                raw[0] = d0 & 0xffffu; raw[1] = d0 >> 16; raw[2] = d1 & 0xffffu; raw[3] = d1 >> 16;
-                raw[4] = d2 & 0xffffu; raw[5] = d2 >> 16; raw[6] = d3 & 0xffffu; raw[7] = d3 >> 16;
+            bool hot = false;
+            [[maybe_unused]] Hot16 h16;
+            if constexpr (VEC == 8 && !STOCH && DEQ_ONLY) {
+                h16 = hot16_scale<DT>(mx, a, s_win);
+                hot = !__any(!h16.ok);
             }
-            const bool slow = (a.force_slow != 0) || !fs.ok;
-            if (__builtin_expect(__any(slow), 0)) {
-                // cold: replay the reference's op sequence step by step (exact for every block)
-                const BlockScale bs = block_scale<DT>(mx, a.mant_bits, a.eps_dt, s_win);
-                e_blk = bs.e;
-                nan_blk = bs.mode == 2;
-                uint32_t outraw[VEC];
+            if (__builtin_expect(hot, 1)) {
+                if constexpr (VEC == 8 && !STOCH && DEQ_ONLY) {
+                    const uint32_t absm = T::ABS | (T::ABS << 16);
+                    const uint32_t dd[4] = {d0, d1, d2, d3};
+                    uint32_t oo[4];
 #pragma unroll
-                for (int j = 0; j < VEC; j++) {
-                    const float dither = STOCH ? uniform24k(rng_item_key(a.seed, (uint64_t)item * VEC), (uint32_t)j) - 0.5f : 0.f;
-                    const float yv = quant_elem<DT>(raw_to_f32<DT>(raw[j]), bs, STOCH, dither, &code[j]);
-                    outraw[j] = f32_to_raw<DT>(yv);
-                }
-                if constexpr (VEC == 4) { o0 = outraw[0]; o1 = outraw[1]; o2 = outraw[2]; o3 = outraw[3]; }
-                else {
-                    o0 = outraw[0] | (outraw[1] << 16); o1 = outraw[2] | (outraw[3] << 16);
-                    o2 = outraw[4] | (outraw[5] << 16); o3 = outraw[6] | (outraw[7] << 16);
+                    for (int x = 0; x < 4; x++) {
+                        const uint32_t am = pk_min_u16(dd[x] & absm, h16.maxv2);          // clamped magnitudes of two elements
+                        float lo, hi;
+                        if constexpr (DT == BFPQ_BF16) {
+                            lo = u2f(am << 16) + h16.C;
+                            hi = u2f(am & 0xffff0000u) + h16.C;
+                        } else {
+                            lo = fma_mix_f16<false>(am, h16.C);                                // (float)half + C, fused
+                            hi = fma_mix_f16<true>(am, h16.C);
+                        }
+                        lo -= h16.C; hi -= h16.C;
+                        uint32_t pk;
+                        if constexpr (DT == BFPQ_BF16) pk = __builtin_amdgcn_perm(f2u(hi), f2u(lo), 0x07060302u);   // exact: upper halves
+                        else pk = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo, hi));                 // exact in fp16
+                        oo[x] = bfi_b32(absm, pk, dd[x]);                                      // magnitude from pk, signs from the input
+                    }
+                    o0 = oo[0]; o1 = oo[1]; o2 = oo[2]; o3 = oo[3];
                 }
             } else {
-                typedef float float2v __attribute__((ext_vector_type(2)));
-                float y[VEC];
-                [[maybe_unused]] const uint32_t rkey = STOCH ? rng_item_key(a.seed, (uint64_t)item * VEC) : 0u;
-#pragma unroll
-                for (int j = 0; j < VEC; j += 2) {                     // two elements per v_pk_mul_f32
-                    float2v x;
-                    if constexpr (DT == BFPQ_BF16) {
-                        const uint32_t d = j < 2 ? d0 : (j < 4 ? d1 : (j < 6 ? d2 : d3));
-                        x = (float2v){u2f(d << 16), u2f(d & 0xffff0000u)};
-                    } else x = (float2v){raw_to_f32<DT>(raw[j]), raw_to_f32<DT>(raw[j + 1])};
-                    float2v t = x * (float2v){fs.inv, fs.inv};
-                    if constexpr (STOCH) {
-                        t.x += uniform24k(rkey, (uint32_t)j) - 0.5f;
-                        t.y += uniform24k(rkey, (uint32_t)j + 1u) - 0.5f;
-                    }
-                    float2v q = {__builtin_amdgcn_fmed3f(rintf(t.x), -fs.qmax, fs.qmax), __builtin_amdgcn_fmed3f(rintf(t.y), -fs.qmax, fs.qmax)};
-                    code[j] = q.x; code[j + 1] = q.y;
-                    const float2v yy = q * (float2v){fs.interval, fs.interval};
-                    y[j] = yy.x; y[j + 1] = yy.y;
+                const FastScale fs = fast_scale<DT>(mx, a.mant_bits, a.eps_dt, s_win);
+                e_blk = fs.e;
+                uint32_t raw[VEC];
+                if constexpr (VEC == 4) { raw[0] = d0; raw[1] = d1; raw[2] = d2; raw[3] = d3; }
+                else {
+                    raw[0] = d0 & 0xffffu; raw[1] = d0 >> 16; raw[2] = d1 & 0xffffu; raw[3] = d1 >> 16;
+                    raw[4] = d2 & 0xffffu; raw[5] = d2 >> 16; raw[6] = d3 & 0xffffu; raw[7] = d3 >> 16;
                 }
-                if constexpr (DT == BFPQ_F32) { o0 = f2u(y[0]); o1 = f2u(y[1]); o2 = f2u(y[2]); o3 = f2u(y[3]); }
-                else if constexpr (DT == BFPQ_BF16) {                 // exact: the bf16 image is the upper half
-                    o0 = __builtin_amdgcn_perm(f2u(y[1]), f2u(y[0]), 0x07060302u);
-                    o1 = __builtin_amdgcn_perm(f2u(y[3]), f2u(y[2]), 0x07060302u);
-                    o2 = __builtin_amdgcn_perm(f2u(y[5]), f2u(y[4]), 0x07060302u);
-                    o3 = __builtin_amdgcn_perm(f2u(y[7]), f2u(y[6]), 0x07060302u);
-                } else {                                               // exact in fp16: any rounding mode packs it
-                    o0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y[0], y[1]));
-                    o1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y[2], y[3]));
-                    o2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y[4], y[5]));
-                    o3 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y[6], y[7]));
+                const bool slow = (a.force_slow != 0) || !fs.ok;
+                if (__builtin_expect(__any(slow), 0)) {
+                    // cold: replay the reference's op sequence step by step (exact for every block)
+                    const BlockScale bs = block_scale<DT>(mx, a.mant_bits, a.eps_dt, s_win);
+                    e_blk = bs.e;
+                    nan_blk = bs.mode == 2;
+                    uint32_t outraw[VEC];
+    #pragma unroll
+                    for (int j = 0; j < VEC; j++) {
+                        const float dither = STOCH ? uniform24k(rng_item_key(a.seed, (uint64_t)item * VEC), (uint32_t)j) - 0.5f : 0.f;
+                        const float yv = quant_elem<DT>(raw_to_f32<DT>(raw[j]), bs, STOCH, dither, &code[j]);
+                        outraw[j] = f32_to_raw<DT>(yv);
+                    }
+                    if constexpr (VEC == 4) { o0 = outraw[0]; o1 = outraw[1]; o2 = outraw[2]; o3 = outraw[3]; }
+                    else {
+                        o0 = outraw[0] | (outraw[1] << 16); o1 = outraw[2] | (outraw[3] << 16);
+                        o2 = outraw[4] | (outraw[5] << 16); o3 = outraw[6] | (outraw[7] << 16);
+                    }
+                } else {
+                    typedef float float2v __attribute__((ext_vector_type(2)));
+                    float y[VEC];
+                    [[maybe_unused]] const uint32_t rkey = STOCH ? rng_item_key(a.seed, (uint64_t)item * VEC) : 0u;
+    #pragma unroll
+                    for (int j = 0; j < VEC; j += 2) {                     // two elements per v_pk_mul_f32
+                        float2v x;
+                        if constexpr (DT == BFPQ_BF16) {
+                            const uint32_t d = j < 2 ? d0 : (j < 4 ? d1 : (j < 6 ? d2 : d3));
+                            x = (float2v){u2f(d << 16), u2f(d & 0xffff0000u)};
+                        } else x = (float2v){raw_to_f32<DT>(raw[j]), raw_to_f32<DT>(raw[j + 1])};
+                        float2v t = x * (float2v){fs.inv, fs.inv};
+                        if constexpr (STOCH) {
+                            t.x += uniform24k(rkey, (uint32_t)j) - 0.5f;
+                            t.y += uniform24k(rkey, (uint32_t)j + 1u) - 0.5f;
+                        }
+                        float2v q = {__builtin_amdgcn_fmed3f(rintf(t.x), -fs.qmax, fs.qmax), __builtin_amdgcn_fmed3f(rintf(t.y), -fs.qmax, fs.qmax)};
+                        code[j] = q.x; code[j + 1] = q.y;
+                        const float2v yy = q * (float2v){fs.interval, fs.interval};
+                        y[j] = yy.x; y[j + 1] = yy.y;
+                    }
+                    if constexpr (DT == BFPQ_F32) { o0 = f2u(y[0]); o1 = f2u(y[1]); o2 = f2u(y[2]); o3 = f2u(y[3]); }
+                    else if constexpr (DT == BFPQ_BF16) {                 // exact: the bf16 image is the upper half
+                        o0 = __builtin_amdgcn_perm(f2u(y[1]), f2u(y[0]), 0x07060302u);
+                        o1 = __builtin_amdgcn_perm(f2u(y[3]), f2u(y[2]), 0x07060302u);
+                        o2 = __builtin_amdgcn_perm(f2u(y[5]), f2u(y[4]), 0x07060302u);
+                        o3 = __builtin_amdgcn_perm(f2u(y[7]), f2u(y[6]), 0x07060302u);
+                    } else {                                               // exact in fp16: any rounding mode packs it
+                        o0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y[0], y[1]));
+                        o1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y[2], y[3]));
+                        o2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y[4], y[5]));
+                        o3 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y[6], y[7]));
+                    }
                 }
             }
         }
@@ -912,6 +981,26 @@ int launch_quant_rows(const void* in, void* out_deq, void* out_codes, int8_t* ou
     return (int)hipGetLastError();
 }
 
+// range of block maxima (dtype exponent field) that the hot16 path of k_fused_flat takes, and its max_v constant; see hot16_scale
+void set_hot16(FusedArgs& a, int dtype, int mant_bits, float eps_dt)
+{
+    a.kb_lo = 1000; a.kb_span = 0; a.maxv_c = 0;            // never
+    if (dtype == BFPQ_F32 || a.force_slow || mant_bits < 1 || mant_bits > (dtype == BFPQ_F16 ? 11 : 8)) return;
+    const int mb = dtype == BFPQ_F16 ? 10 : 7, eoff = dtype == BFPQ_F16 ? 112 : 0;
+    int lo = 1 + eoff, hi = (dtype == BFPQ_F16 ? 30 : 254) + eoff;     // fp32-biased exponent field of the block max: normal, finite
+    while (lo <= hi && !(eps_dt < ldexpf(1.0f, lo - 127 - mb - 1))) lo++;   // max + epsilon rounds back to max
+    if (lo < mant_bits + 3) lo = mant_bits + 3;              // interval >= 2^-124
+    if (lo < eoff + 2) lo = eoff + 2;                        // max_v = (2^m - 1) 2^(e-m) >= 2^(e-1) is a NORMAL number of the dtype
+    if (dtype == BFPQ_F16 && lo < 103 + mant_bits) lo = 103 + mant_bits;    // interval >= 2^-24, the smallest fp16
+    if (hi > 253) hi = 253;                                  // e <= max exponent + 1 stays finite
+    if (hi > 230 + mant_bits) hi = 230 + mant_bits;          // the magic constant 1.5 * 2^(23 + e - m) stays finite
+    if (dtype == BFPQ_F16 && hi > 141) hi = 141;             // 2^e finite in fp16
+    if (lo > hi) return;
+    a.kb_lo = lo - eoff; a.kb_span = hi - lo;
+    const uint32_t mpat = ((1u << (mant_bits - 1)) - 1u) << (mb - (mant_bits - 1));
+    a.maxv_c = mpat - ((uint32_t)(1 + eoff) << mb);
+}
+
 bool fused_shape_ok(int64_t rows, int64_t cols, int dtype, int block_size, int N, int M)
 {
     (void)N;
@@ -1056,6 +1145,7 @@ int bfpq_quantize_nm(const void* in, void* out_deq, void* out_codes, int8_t* out
         a.lpb = block_size ? block_size / dtype_vec(dtype) : 0;
         a.mant_bits = mant_bits; a.N = N; a.code_bits = code_bits;
         a.force_slow = mant_bits > (dtype == BFPQ_F32 ? 24 : (dtype == BFPQ_F16 ? 11 : 8));
+        set_hot16(a, dtype, mant_bits, eps_dt);
         a.selws = nullptr;
         if (dtype == BFPQ_F32) return launch_fused<BFPQ_F32>(a, M, sparsify_first != 0, s);
         if (dtype == BFPQ_F16) return launch_fused<BFPQ_F16>(a, M, sparsify_first != 0, s);
@@ -1076,6 +1166,7 @@ int bfpq_quantize_nm(const void* in, void* out_deq, void* out_codes, int8_t* out
             a.lpb = block_size / dtype_vec(dtype);
             a.mant_bits = mant_bits; a.N = 0; a.code_bits = code_bits;
             a.force_slow = mant_bits > (dtype == BFPQ_F32 ? 24 : (dtype == BFPQ_F16 ? 11 : 8));
+            set_hot16(a, dtype, mant_bits, eps_dt);
             a.selws = nullptr;
             if (dtype == BFPQ_F32) return launch_fused<BFPQ_F32>(a, 0, true, s);
             if (dtype == BFPQ_F16) return launch_fused<BFPQ_F16>(a, 0, true, s);
@@ -1133,6 +1224,7 @@ int bfpq_quantize_threshold(const void* in, void* out_deq, void* out_codes, int8
         a.lpb = block_size / dtype_vec(dtype);
         a.mant_bits = mant_bits; a.N = 0; a.code_bits = code_bits;
         a.force_slow = mant_bits > (dtype == BFPQ_F32 ? 24 : (dtype == BFPQ_F16 ? 11 : 8));
+        set_hot16(a, dtype, mant_bits, eps_dt);
         a.selws = (SelWs*)ws;
         if (dtype == BFPQ_F32) return launch_fused_threshold<BFPQ_F32>(a, s);
         if (dtype == BFPQ_F16) return launch_fused_threshold<BFPQ_F16>(a, s);

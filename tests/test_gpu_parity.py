@@ -848,3 +848,31 @@ def test_unstructured_graph_replay_odd_call_count():
     torch.cuda.synchronize()
     for o, w in zip(outs, want):
         assert torch.equal(o, w)
+
+
+@pytest.mark.parametrize("dname", ["bf16", "f16"])
+def test_every_block_max_pattern_dropin(dname):
+    """drop-in quantizer over EVERY finite 16-bit magnitude as the block max (all exponent windows, the epsilon-dominated
+    tiny maxima, subnormals, the largest finite values) with full-range and tiny block mates, both signs, for several
+    mantissa widths and epsilons: the lean hot path, the general fast path and the step-by-step replay must all give the
+    oracle's bits (reference bfp_ops.py:29-44)."""
+    dt = DT[dname]
+    hi = 0x7F80 if dname == "bf16" else 0x7C00
+    pat = np.arange(0, hi, dtype=np.uint16)
+    n = pat.size
+    rng = np.random.default_rng(5)
+    blk = np.zeros((n, 64), dtype=np.uint16)
+    blk[:, 0] = pat
+    for j in range(1, 64):                                   # mates: magnitudes <= the max, random exponent drop, random sign
+        drop = rng.integers(0, 40, size=n).astype(np.int64) * (1 << (7 if dname == "bf16" else 10))
+        m = np.maximum(pat.astype(np.int64) - drop - rng.integers(0, 128, size=n), 0)
+        blk[:, j] = (m.astype(np.uint16)) | (rng.integers(0, 2, size=n).astype(np.uint16) << 15)
+    blk[:, 0] |= (rng.integers(0, 2, size=n).astype(np.uint16) << 15)
+    xc = from_bits(blk.reshape(-1), dt).view(n, 64)
+    x = xc.to(DEV)
+    for m, eps in ((3, 1e-8), (7, 1e-8), (1, 1e-8), (8, 1e-8), (3, 0.0), (5, 1e-3)):
+        got = bfp_ops._no_sparsity_float_to_bfp(x, 64, m, eps, 'determ', 'cuda')
+        want = O.no_sparsity_float_to_bfp(xc, 64, m, eps)
+        assert_bits_equal(bits(got), bits(want), dt, f"{dname} m={m} eps={eps}")
+    got = bfp_ops._no_sparsity_float_to_bfp(x.view(-1, 16), 16, 3, 1e-8, 'determ', 'cuda')          # other lane-group widths
+    assert_bits_equal(bits(got), bits(O.no_sparsity_float_to_bfp(xc.view(-1, 16), 16, 3, 1e-8)), dt, f"{dname} block 16")
