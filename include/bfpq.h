@@ -100,6 +100,17 @@ int bfpq_quantize_nm(const void* in_dev, void* out_deq_dev, void* out_codes_dev,
                      const uint8_t* exp_win_dev, const uint8_t* nm4_lut_dev,
                      void* scratch_dev, void* stream);
 
+/* The drop-in call with its constants bound once (what a module's forward issues per tensor): the same work as
+ * bfpq_quantize_nm(in, out, NULL, NULL, rows, cols, plan->...) in round-half-even mode, six arguments instead of nineteen.
+ * Shapes that need the two-launch general path work in place through out_dev (no scratch). */
+typedef struct bfpq_plan {
+    int dtype, block_size, mant_bits, N, M, sparsify_first;
+    double epsilon;
+    const uint8_t* exp_win_dev;   /* BFPQ_EXP_WIN_ENTRIES, for dtype (NULL when block_size == 0) */
+    const uint8_t* nm_lut_dev;    /* bfpq_nm4_lut_host(N) for M == 4, bfpq_nm8_lut_host(N) or NULL for M == 8, else NULL */
+} bfpq_plan;
+int bfpq_fake_quantize(const bfpq_plan* plan_host, const void* in_dev, void* out_dev, int64_t rows, int64_t cols, void* stream);
+
 /* returns 1 if bfpq_quantize_nm would take the single-pass fused kernel for this problem */
 int bfpq_is_fused(int64_t rows, int64_t cols, int dtype, int block_size, int N, int M);
 

@@ -39,8 +39,10 @@ def _quantize_nm_ref_dtype(t, block_size, mant_bits, epsilon, rounding_mode, N=0
     """quantize_nm with the reference's output dtype: 'stoc' on a half tensor comes back as fp32.
     The single-pass kernel writes that fp32 image directly; other shapes convert afterwards."""
     seed = _seed_for(rounding_mode)
-    if seed == 0:                                      # round-half-even: the registered (traceable) op
-        return torch.ops.bfpq.fake_quantize(t, int(block_size), int(mant_bits), float(epsilon), int(N), int(M), bool(sparsify_first), 0)
+    if seed == 0:                                      # round-half-even
+        if torch.compiler.is_compiling():              # under torch.compile / export: the registered (traceable) op
+            return torch.ops.bfpq.fake_quantize(t, int(block_size), int(mant_bits), float(epsilon), int(N), int(M), bool(sparsify_first), 0)
+        return _fast_quant(block_size, mant_bits, epsilon, N, M, sparsify_first)(t)
     src = t.contiguous()
     if seed and t.dtype != torch.float32 and t.numel() and block_size > 0 and native.is_fused(src, block_size, N, M):
         _, y, _ = native.quantize_nm(src, block_size, mant_bits, epsilon, N=N, M=M, sparsify_first=sparsify_first,
@@ -48,6 +50,18 @@ def _quantize_nm_ref_dtype(t, block_size, mant_bits, epsilon, rounding_mode, N=0
         return y.view(t.shape)
     y, _, _ = native.quantize_nm(src, block_size, mant_bits, epsilon, N=N, M=M, sparsify_first=sparsify_first, stoch_seed=seed)
     return _stoc_dtype(y.view(t.shape), rounding_mode)
+
+
+_fast_quants = {}
+
+
+def _fast_quant(block_size, mant_bits, epsilon, N, M, sparsify_first):
+    """the bound form of the drop-in call for one configuration (native.FastQuant), made once"""
+    key = (block_size, mant_bits, epsilon, N, M, sparsify_first)
+    f = _fast_quants.get(key)
+    if f is None:
+        f = _fast_quants[key] = native.FastQuant(block_size, mant_bits, epsilon, N, M, sparsify_first)
+    return f
 
 
 def _stoc_dtype(t, mode):
@@ -343,31 +357,71 @@ def _get_op_name(name, epsilon, mant_bits, rounding_mode, **kwargs):
     return '%s_BFP_%s_%d' % (name, rounding_mode, mant_bits)
 
 
-class WeightCache:
-    """Opt-in cache of the quantized (and sparsified) weight operand, keyed on the parameter's identity,
-    in-place version counter, dtype and device.  The reference re-runs the whole path on the unchanged weight in
-    every forward (bfp_ops.py:151-166, 7 Linear layers per LLaMA block); with the cache an inference loop
-    quantizes each weight once.  Off by default (reference semantics); stochastic rounding is never cached."""
+_CACHE_KEYS = ('mant_bits', 'epsilon', 'rounding_mode', 'block_size', 'num_format', 'weight_mant_bits', 'w_sparsity',
+               'sparsity_frac', 'N', 'M', 'sparsity_num_format', 'first', 'sparsity_mode')
 
-    def __init__(self):
+
+class WeightCache:
+    """Opt-in, INFERENCE-ONLY cache of the quantized (and sparsified) weight operand.  The reference re-runs the whole
+    path on the unchanged weight in every forward (bfp_ops.py:151-166, 7 Linear layers per LLaMA block); with the cache an
+    inference loop quantizes each weight once.  Off by default (reference semantics).
+    Valid while (storage pointer, in-place version counter, dtype, device, shape, the configuration values that shape
+    the weight operand) are unchanged.  It is BYPASSED whenever a stale entry could go unnoticed: while gradients are being
+    recorded for the weight, or the owning module is in training mode (optimizers and EMA code update `p.data` in place,
+    which does not bump the version counter), and for stochastic rounding.  After such an update in eval mode call
+    invalidate()."""
+
+    def __init__(self, module=None):
+        import weakref
         self.key = None
         self.value = None
         self.hits = 0
         self.misses = 0
+        self._module = weakref.ref(module) if module is not None else None
+
+    @staticmethod
+    def _key(w, bfp_args):
+        return (w.data_ptr(), w._version, w.dtype, w.device, tuple(w.shape), tuple(bfp_args.get(k) for k in _CACHE_KEYS))
+
+    def usable(self, w, bfp_args):
+        if bfp_args.get('rounding_mode') != rounding_modes.DETERM:
+            return False
+        if torch.is_grad_enabled() and w.requires_grad:
+            return False
+        m = self._module() if self._module is not None else None
+        return not (m is not None and m.training)
 
     def lookup(self, w, bfp_args):
-        if bfp_args.get('rounding_mode') != rounding_modes.DETERM:
+        if not self.usable(w, bfp_args):
             return None
-        key = (w.data_ptr(), w._version, w.dtype, w.device, tuple(w.shape))
-        if self.key == key:
+        if self.key == self._key(w, bfp_args):
             self.hits += 1
-            return self.value
+            return self.value.view_as(self.value)            # a fresh alias: the stored tensor never enters an autograd graph
         return None
 
-    def store(self, w, wq):
-        self.key = (w.data_ptr(), w._version, w.dtype, w.device, tuple(w.shape))
+    def store(self, w, wq, bfp_args=None):
+        bfp_args = bfp_args or {}
+        if bfp_args and not self.usable(w, bfp_args):
+            return
+        self.key = self._key(w, bfp_args)
         self.value = wq.detach()
         self.misses += 1
+
+    def invalidate(self):
+        self.key = None
+        self.value = None
+
+
+def _quantize_operands(x, w, transpose, bfp_args, cache):
+    """(Q_in(x), Q_w(w)) -- reference MxM_pre_processing (bfp_ops.py:151-155), with the optional weight cache"""
+    if cache is None:
+        return MxM_pre_processing(x, w, transpose, **bfp_args)
+    xq = float_to_bfp_blocked(x, **bfp_args, identifier='in')
+    wq = cache.lookup(w, bfp_args)
+    if wq is None:
+        wq = _quantize_weight_operand(w, transpose, bfp_args)
+        cache.store(w, wq, bfp_args)
+    return xq, wq
 
 
 class _OperandQuantizer(torch.autograd.Function):
@@ -375,14 +429,7 @@ class _OperandQuantizer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, transpose, bfp_args, cache):
-        if cache is None:
-            return MxM_pre_processing(x, w, transpose, **bfp_args)
-        xq = float_to_bfp_blocked(x, **bfp_args, identifier='in')
-        wq = cache.lookup(w, bfp_args)
-        if wq is None:
-            wq = _quantize_weight_operand(w, transpose, bfp_args)
-            cache.store(w, wq)
-        return xq, wq
+        return _quantize_operands(x, w, transpose, bfp_args, cache)
 
     @staticmethod
     def backward(ctx, grad_x, grad_w):
@@ -413,6 +460,9 @@ def _gen_bfp_op(op, name, bfp_args, transpose=False, cache=None):
     """reference: bfp_ops.py:160-192 -- wraps `op(x, w, ...)` so that both operands are BFP-quantized
     (and sparsified) on the way in and the output gradient on the way back.  cache: optional WeightCache."""
     def bfp_op(x, w, *args, **kwargs):
+        if not torch.is_grad_enabled():                 # inference: same values, no autograd nodes to build
+            xq, wq = _quantize_operands(x, w, transpose, bfp_args, cache)
+            return op(xq, wq, *args, **kwargs)
         xq, wq = _OperandQuantizer.apply(x, w, transpose, bfp_args, cache)
         return _GradQuantizer.apply(op(xq, wq, *args, **kwargs), bfp_args)
 
@@ -464,7 +514,7 @@ class _BFPModule:
 
     def enable_weight_cache(self, enabled=True):
         """opt in to (or out of) caching the quantized weight across forwards; see WeightCache"""
-        cache = WeightCache() if enabled else None
+        cache = WeightCache(self) if enabled else None
         op = _get_bfp_op(self._functional, self._op_name, self.bfp_args, cache=cache)
         if hasattr(self, 'linear_op'):
             self.linear_op = op

@@ -348,18 +348,15 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
 #pragma unroll
                     for (int x = 0; x < 4; x++) {
                         const uint32_t am = pk_min_u16(dd[x] & absm, h16.maxv2);          // clamped magnitudes of two elements
-                        float lo, hi;
-                        if constexpr (DT == BFPQ_BF16) {
-                            lo = u2f(am << 16) + h16.C;
-                            hi = u2f(am & 0xffff0000u) + h16.C;
-                        } else {
-                            lo = fma_mix_f16<false>(am, h16.C);                                // (float)half + C, fused
-                            hi = fma_mix_f16<true>(am, h16.C);
-                        }
-                        lo -= h16.C; hi -= h16.C;
+                        typedef float float2v __attribute__((ext_vector_type(2)));
+                        const float2v C2 = {h16.C, h16.C};
+                        float2v v;
+                        if constexpr (DT == BFPQ_BF16) v = (float2v){u2f(am << 16), u2f(am & 0xffff0000u)} + C2;   // v_pk_add_f32
+                        else v = (float2v){fma_mix_f16<false>(am, h16.C), fma_mix_f16<true>(am, h16.C)};            // (float)half + C, fused
+                        v -= C2;
                         uint32_t pk;
-                        if constexpr (DT == BFPQ_BF16) pk = __builtin_amdgcn_perm(f2u(hi), f2u(lo), 0x07060302u);   // exact: upper halves
-                        else pk = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(lo, hi));                 // exact in fp16
+                        if constexpr (DT == BFPQ_BF16) pk = __builtin_amdgcn_perm(f2u(v.y), f2u(v.x), 0x07060302u);  // exact: upper halves
+                        else pk = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));                // exact in fp16
                         oo[x] = bfi_b32(absm, pk, dd[x]);                                      // magnitude from pk, signs from the input
                     }
                     o0 = oo[0]; o1 = oo[1]; o2 = oo[2]; o3 = oo[3];
@@ -1190,6 +1187,13 @@ int bfpq_quantize_nm(const void* in, void* out_deq, void* out_codes, int8_t* out
     rc = quantize_stage(in, tmp);
     if (rc) return rc;
     return launch_nm_rows(tmp, tmp, out_codes, code_bits, rows, cols, dtype, N, M, M == 8 ? nm4_lut : nullptr, s);
+}
+
+int bfpq_fake_quantize(const bfpq_plan* p, const void* in, void* out, int64_t rows, int64_t cols, void* stream)
+{
+    if (!p) return BFPQ_E_ARG;
+    return bfpq_quantize_nm(in, out, nullptr, nullptr, rows, cols, p->dtype, p->block_size, p->mant_bits, p->epsilon, p->N, p->M,
+                            p->sparsify_first, 0, 0, p->exp_win_dev, p->nm_lut_dev, nullptr, stream);
 }
 
 int bfpq_nm_sparsify(const void* in, void* out, int64_t rows, int64_t cols, int dtype, int N, int M,

@@ -73,6 +73,7 @@ def load_library():
         L.bfpq_nm_prune_mask_host.argtypes = [vp, i32, i32]
         L.bfpq_nm_prune_mask_host.restype = u64
         L.bfpq_quantize_nm.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, dbl, i32, i32, i32, i32, u64, vp, vp, vp, vp]
+        L.bfpq_fake_quantize.argtypes = [vp, vp, vp, i64, i64, vp]
         L.bfpq_is_fused.argtypes = [i64, i64, i32, i32, i32, i32]
         L.bfpq_nm_sparsify.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp]
         L.bfpq_select_passes.argtypes = [i32]
@@ -91,7 +92,7 @@ def load_library():
         L.bfpq_hbfp_linear_decode.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
         L.bfpq_hbfp_linear_tiled_ok.argtypes = [i64, i64]
         L.bfpq_hbfp_linear_decode_tiled.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
-        for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
+        for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_is_fused", "bfpq_nm_sparsify",
                      "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
                      "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize", "bfpq_hbfp_linear_slices",
                      "bfpq_hbfp_linear_decode", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled"):
@@ -101,7 +102,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_select_ws_bytes", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24",
-                    "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_is_fused", "bfpq_nm_sparsify",
+                    "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_is_fused", "bfpq_nm_sparsify",
                     "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
                     "bfpq_threshold_apply", "bfpq_quantize_threshold")
 
@@ -231,6 +232,65 @@ def quantize_nm(t, block_size, mant_bits, epsilon, N=0, M=0, sparsify_first=True
                                 _ptr(win), _ptr(lut), _ptr(scratch), _stream(src))
         check(rc, "bfpq_quantize_nm")
     return deq, codes, exps
+
+
+class _Plan(ctypes.Structure):
+    """include/bfpq.h: bfpq_plan"""
+    _fields_ = [("dtype", ctypes.c_int), ("block_size", ctypes.c_int), ("mant_bits", ctypes.c_int), ("N", ctypes.c_int),
+                ("M", ctypes.c_int), ("sparsify_first", ctypes.c_int), ("epsilon", ctypes.c_double),
+                ("exp_win_dev", ctypes.c_void_p), ("nm_lut_dev", ctypes.c_void_p)]
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+class FastQuant:
+    """The drop-in call (round-half-even, dequantised tensor out) with everything constant bound once: per call it costs
+    one output allocation and one six-argument ctypes call (bfpq_fake_quantize).  This is what the module wrappers issue
+    per tensor; native.quantize_nm stays the general entry point."""
+
+    __slots__ = ("block_size", "mant_bits", "epsilon", "N", "M", "sparsify_first", "_plans", "_fn")
+
+    def __init__(self, block_size, mant_bits, epsilon, N=0, M=0, sparsify_first=True):
+        self.block_size, self.mant_bits, self.epsilon = int(block_size), int(mant_bits), float(epsilon)
+        self.N, self.M = (int(N), int(M)) if 0 < N < M else (0, 0)
+        self.sparsify_first = bool(sparsify_first)
+        self._plans = {}
+        self._fn = load_library().bfpq_fake_quantize
+
+    def _plan(self, dtype, dev):
+        key = (dtype, dev.index)
+        p = self._plans.get(key)
+        if p is None:
+            win = exp_window_dev(dtype, dev) if self.block_size > 0 else None
+            lut = nm4_lut_dev(self.N, dev) if self.M == 4 else (nm8_lut_dev(self.N, dev) if (self.M == 8 and USE_NM8_TABLE) else None)
+            plan = _Plan(DTYPE_CODE[dtype], self.block_size, self.mant_bits, self.N, self.M, 1 if self.sparsify_first else 0,
+                         self.epsilon, win.data_ptr() if win is not None else None, lut.data_ptr() if lut is not None else None)
+            p = self._plans[key] = (plan, ctypes.addressof(plan), win, lut)        # (the tensors are kept alive with the plan)
+        return p
+
+    def __call__(self, t, out=None):
+        if t.device.type != "cuda" or t.dtype not in DTYPE_CODE:
+            require_device_tensor(t)
+        if self.block_size == 0 and self.M == 0:
+            return t
+        src = t if t.is_contiguous() else t.contiguous()
+        dst = torch.empty_like(src) if out is None else out
+        n = src.numel()
+        if n == 0:
+            return dst
+        dev = src.device
+        cols = src.shape[-1] if src.dim() else 1
+        plan = self._plan(src.dtype, dev)
+        if torch.cuda.current_device() != dev.index:
+            with torch.cuda.device(dev):
+                rc = self._fn(plan[1], src.data_ptr(), dst.data_ptr(), n // cols, cols, torch.cuda.current_stream(dev).cuda_stream)
+        else:
+            stream = _raw_stream(dev.index) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream
+            rc = self._fn(plan[1], src.data_ptr(), dst.data_ptr(), n // cols, cols, stream)
+        if rc:
+            check(rc, "bfpq_fake_quantize")
+        return dst
 
 
 class SelectWorkspace:

@@ -483,24 +483,43 @@ def test_graph_capture_and_side_stream():
 
 
 def test_weight_cache_opt_in():
-    """§8f next #1: cached quantized weight == re-quantized weight; invalidated by an in-place update"""
+    """§8f next #1: the cached quantized weight == the re-quantized weight.  The cache is inference-only: it is bypassed
+    while gradients are recorded for the weight and in training mode (optimizers write p.data in place without bumping the
+    version counter), keyed on the configuration as well as on the parameter, and explicitly invalidatable."""
     kw = cfg(mant_bits=7, block_size=32, N=2, M=4, w_sparsity=True)
     lin = bfp_ops.BFPLinear(64, 128, True, **dict(kw)).to(DEV)
     ref = bfp_ops.BFPLinear(64, 128, True, **dict(kw)).to(DEV)
     ref.load_state_dict(lin.state_dict())
     lin.enable_weight_cache()
+    cache = lin.linear_op.weight_cache
     x = synth(10, 64, torch.float32, 1.0).to(DEV).requires_grad_(True)
     x2 = x.detach().clone().requires_grad_(True)
-    for it in range(3):
-        y, yr = lin(x), ref(x2)
-        assert torch.equal(y, yr)
-    cache = lin.linear_op.weight_cache
-    assert cache.misses == 1 and cache.hits == 2
+    # training-style forward/backward: cache bypassed, gradients as without it
+    y, yr = lin(x), ref(x2)
+    assert torch.equal(y, yr) and cache.hits == 0 and cache.misses == 0
     y.sum().backward(); yr.sum().backward()
     assert torch.equal(x.grad, x2.grad) and torch.equal(lin.weight.grad, ref.weight.grad)     # straight-through to w
+    # an optimizer-style update through .data does not bump the version counter; in training mode nothing is cached, so
+    # the next forward sees the new weight
+    lin.weight.data.add_(0.01); ref.weight.data.add_(0.01)
+    assert torch.equal(lin(x), ref(x2))
+    lin.eval(); ref.eval()
     with torch.no_grad():
+        for it in range(3):
+            assert torch.equal(lin(x), ref(x2))
+        assert cache.misses == 1 and cache.hits == 2
+        first = lin(x)
+        assert first.grad_fn is None
         lin.weight.add_(0.01); ref.weight.add_(0.01)                                           # bumps weight._version
-    assert torch.equal(lin(x), ref(x2)) and cache.misses == 2
+        assert torch.equal(lin(x), ref(x2)) and cache.misses == 2
+        lin.weight.data.mul_(1.5); ref.weight.data.mul_(1.5)                                   # silent update: stale until invalidated
+        cache.invalidate()
+        assert torch.equal(lin(x), ref(x2)) and cache.misses == 3
+        lin.bfp_args['mant_bits'] = 3; ref.bfp_args['mant_bits'] = 3                            # the configuration is part of the key
+        assert torch.equal(lin(x), ref(x2)) and cache.misses == 4
+        lin.train()
+        h = cache.hits
+        assert torch.equal(lin(x), ref(x2)) and cache.hits == h                                 # training mode: bypassed
     lin.enable_weight_cache(False)
     assert lin.linear_op.weight_cache is None and torch.equal(lin(x), ref(x2))
 

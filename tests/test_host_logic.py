@@ -185,9 +185,18 @@ def test_bfpconfig_roundtrip(tmp_path):
     assert pkg.BFPConfig.from_yaml(p) == c
     assert pkg.BFPConfig.from_dict(dict(kw, bfp_tile_size=3)) == c   # unknown keys tolerated
     d = bfp_util.get_bfp_args()
-    assert d['num_format'] == 'bfp' and set(d) <= set(pkg.BFPConfig.keys())
-    assert bfp_util.extract_sparsity_args(d) == dict(sparsity=True, device='cuda', sparsity_mode='structured', sparsity_frac=0.5, N=2, M=4)
-    assert bfp_util.extract_mx_args(d)['block_size'] == 64
+    # the shipped default file carries the reference's 21 keys AND values (src/transformers/bfp/bfp_config.yaml:1-21)
+    assert d == dict(num_format='bfp', sparsity_num_format='fp32', rounding_mode='stoc', epsilon=1e-8, mant_bits=7,
+                     weight_mant_bits=15, block_size=32, in_sparsity=False, w_sparsity=False, grad_sparsity=False,
+                     sparsity_frac=0.5, N=2, M=4, first='s', sparsity_mode='structured', mx_w_elem_format='fp8_e4m3',
+                     mx_a_elem_format='fp8_e4m3', bfloat=16, scale_bits=8, device='cuda')
+    assert set(d) <= set(pkg.BFPConfig.keys())
+    assert bfp_util.extract_sparsity_args(d) == dict(sparsity=False, device='cuda', sparsity_mode='structured', sparsity_frac=0.5, N=2, M=4)
+    assert bfp_util.extract_mx_args(d)['block_size'] == 32
+    import os
+    h = bfp_util.get_bfp_args(os.path.join(os.path.dirname(bfp_util.__file__), 'bfp_config_headline.yaml'))   # the BASELINE.json workload
+    assert (h['mant_bits'], h['block_size'], h['w_sparsity'], h['N'], h['M'], h['rounding_mode'], h['sparsity_num_format']) == \
+        (3, 64, True, 2, 4, 'determ', 'bfp')
 
 
 def test_modules_keep_stock_state_dict_and_identity_cases():
