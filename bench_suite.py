@@ -47,15 +47,70 @@ CASES = [
 ]
 
 
+def model_rows(args, dev):
+    """whole-configuration passes (BASELINE.json configs 1, 3, 4, 5 say "all Linear weights"): every Linear weight of the
+    model through ONE call of float_to_bfp_blocked_many (a list of tensors per launch), timed with HIP events around the
+    eager call; synthetic weights drawn on the device (randn * 0.02).  B/elem as in the single-tensor rows."""
+    def llama(h, inter, layers):
+        return [(h, h)] * 4 * layers + [(inter, h)] * 2 * layers + [(h, inter)] * layers
+    vit = [(1024, 1024)] * 4 * 24 + [(4096, 1024)] * 24 + [(1024, 4096)] * 24
+    opt = [(768, 768)] * 4 * 12 + [(3072, 768)] * 12 + [(768, 3072)] * 12
+    models = [
+        ("cfg1 OPT-125m: all 72 Linear weights, f32 HBFP8 b32 dense", opt, "f32", 8, dict(mant_bits=7, block_size=32), 'w'),
+        ("cfg3 LLaMA-7B: all 224 Linear weights, bf16 HBFP4 b64 2:4 s", llama(4096, 11008, 32), "bf16", 4, dict(w_sparsity=True), 'w'),
+        ("cfg4 LLaMA-13B: all 280 Linear weights, bf16 HBFP4 b64 + 50% unstructured s", llama(5120, 13824, 40), "bf16", 4,
+         dict(w_sparsity=True, sparsity_mode='unstructured'), 'w'),
+        ("cfg5 ViT-L/16: all 144 attention+MLP weights, f32 HBFP8 b16 1:4", vit, "f32", 8, dict(mant_bits=7, block_size=16, N=1, M=4, w_sparsity=True), 'w'),
+        ("cfg5 ViT-L/16: the 144 Linear inputs of one forward [8,197,C], f32 HBFP8 b16 (identifier in)",
+         [(8 * 197, 1024)] * 5 * 24 + [(8 * 197, 4096)] * 24, "f32", 8, dict(mant_bits=7, block_size=16, N=1, M=4, w_sparsity=True), 'in'),
+    ]
+    out = []
+    for name, shapes, dname, bpe, kw, ident in models:
+        if args.only and args.only not in name:
+            continue
+        dt = DT[dname]
+        c = cfg(**kw)
+        g = torch.Generator(device=dev).manual_seed(1234)
+        ws = [(torch.randn(r, cc, generator=g, device=dev) * 0.02).to(dt) for r, cc in shapes]
+        numel = sum(w.numel() for w in ws)
+
+        prep = bfp_ops.PreparedMany(ws, identifier=ident, **c)      # outputs + descriptors bound once (the weights stay put)
+
+        def run():
+            return prep.run()
+        run(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(max(3, args.rounds)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); res = run(); e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+            del res
+        us = statistics.median(ts)
+        gbps = numel * bpe / us / 1e3
+        out.append(dict(case=name, tensors=len(ws), elems=numel, dtype=dname, us_per_pass=us, elems_per_s=numel / us * 1e6,
+                        algorithmic_bytes_per_elem=bpe, achieved_GBps=gbps, frac_of_8TBps=gbps / 8000, launch="eager, prepared list (one launch per 64 tensors)"))
+        print(f"{name:100s} {us:10.1f} us/pass  {numel/us/1e3:8.1f} Gelem/s  {gbps:7.0f} GB/s ({gbps/80:5.1f}%)", flush=True)
+        del ws
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "suite.json"))
     ap.add_argument("--launches", type=int, default=40)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--models", action="store_true", help="also (or with --models-only: only) the whole-model passes")
+    ap.add_argument("--models-only", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     results = []
+    if args.models_only:
+        results = model_rows(args, dev)
+        os.makedirs(os.path.dirname(args.out), exist_ok=True)
+        json.dump(results, open(args.out, "w"), indent=1)
+        return
     for name, rows, cols, dname, bpe, kw in CASES:
         if args.only and args.only not in name:
             continue
@@ -100,6 +155,8 @@ def main():
         print(f"{name:78s} {us:9.2f} us  {numel/us/1e3:8.1f} Gelem/s  {gbps:7.0f} GB/s ({gbps/80:5.1f}%)  {mode}", flush=True)
         del ins
         torch.cuda.empty_cache()
+    if args.models:
+        results += model_rows(args, dev)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(results, open(args.out, "w"), indent=1)
 

@@ -111,6 +111,14 @@ typedef struct bfpq_plan {
 } bfpq_plan;
 int bfpq_fake_quantize(const bfpq_plan* plan_host, const void* in_dev, void* out_dev, int64_t rows, int64_t cols, void* stream);
 
+/* A LIST of tensors in as few launches as possible (up to 64 tensors per launch, their descriptors travel as kernel
+ * arguments: no device memory, graph-capturable).  All tensors share the plan (dtype, block, mantissa width, N:M); apply_nm
+ * says per tensor whether the plan's N:M pruning applies (a Linear's weight) or not (its activation).  What a model pass
+ * issues for "all Linear weights", and what one BFPLinear forward issues for its activation + weight.  Tensors whose
+ * shape the single-pass kernel does not take (ragged rows, M = 8, ...) are handled one by one inside the call. */
+typedef struct bfpq_tensor_desc { const void* in_dev; void* out_dev; int64_t rows, cols; int apply_nm; int reserved; } bfpq_tensor_desc;
+int bfpq_fake_quantize_batched(const bfpq_plan* plan_host, const bfpq_tensor_desc* descs_host, int n, void* stream);
+
 /* returns 1 if bfpq_quantize_nm would take the single-pass fused kernel for this problem */
 int bfpq_is_fused(int64_t rows, int64_t cols, int dtype, int block_size, int N, int M);
 

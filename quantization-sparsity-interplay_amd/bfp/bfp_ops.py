@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from .. import native
 from .. import ops as _ops          # registers torch.ops.bfpq.* (traceable entry points)
 
-__all__ = ["rounding_modes", "round_tensor", "get_exponent", "float_to_bfp_blocked", "float_to_bfp_packed",
+__all__ = ["rounding_modes", "round_tensor", "get_exponent", "float_to_bfp_blocked", "float_to_bfp_blocked_many", "PreparedMany", "float_to_bfp_packed",
            "sparsify", "unpack_bfp_args", "F_linear_bfp", "F_matmul_bfp", "BFPLinear", "BFPConv2d", "WeightCache", "PackedBFP"]
 
 
@@ -226,6 +226,63 @@ def float_to_bfp_blocked(t, mant_bits, epsilon, rounding_mode, device, block_siz
 
 
 # ---- additive public surface (no counterpart in the reference) -------------------------------
+def float_to_bfp_blocked_many(tensors, identifier='', **bfp_args):
+    """float_to_bfp_blocked (bfp_ops.py:124-149) for a LIST of tensors with one configuration -- e.g. every Linear weight of
+    a model -- in as few launches as possible (one per 64 tensors per dtype/device for the 'bfp' format with structured or no
+    pruning and round-half-even; anything else is done tensor by tensor).  Returns the list of results in order."""
+    a = unpack_bfp_args(dict(bfp_args))
+    tensors = list(tensors)
+    sparsity = _select_sparsity(a['in_sparsity'], a['w_sparsity'], a['grad_sparsity'], identifier)
+    lean = (a['num_format'] == 'bfp' and a['sparsity_num_format'] == 'bfp' and a['rounding_mode'] == rounding_modes.DETERM
+            and a['block_size'] > 0 and not bfp_args.get('sgd_update')
+            and (not sparsity or (a['sparsity_mode'] == 'structured' and 0 < a['N'] <= a['M'])))
+    if not lean:
+        return [float_to_bfp_blocked(t, **a, identifier=identifier, sgd_update=bool(bfp_args.get('sgd_update'))) for t in tensors]
+    nm = sparsity and a['N'] < a['M']
+    f = _fast_quant(a['block_size'], a['mant_bits'], a['epsilon'], a['N'] if nm else 0, a['M'] if nm else 0, a['first'] == 's')
+    out = [None] * len(tensors)
+    groups = {}
+    for i, t in enumerate(tensors):
+        native.require_device_tensor(t)
+        groups.setdefault((t.device, t.dtype), []).append(i)
+    for idx in groups.values():
+        for i, y in zip(idx, f.many([tensors[i] for i in idx])):
+            out[i] = y.view(tensors[i].shape)
+    return out
+
+
+class PreparedMany:
+    """float_to_bfp_blocked_many with the per-call host work done once: run() re-quantizes the bound tensors (whose storage
+    must stay put, e.g. a model's weights) into the same output tensors -- one launch per 64 tensors, one ctypes call per
+    dtype/device group."""
+
+    def __init__(self, tensors, identifier='', **bfp_args):
+        a = unpack_bfp_args(dict(bfp_args))
+        self.tensors = list(tensors)
+        self._args, self._ident = a, identifier
+        sparsity = _select_sparsity(a['in_sparsity'], a['w_sparsity'], a['grad_sparsity'], identifier)
+        lean = (a['num_format'] == 'bfp' and a['sparsity_num_format'] == 'bfp' and a['rounding_mode'] == rounding_modes.DETERM
+                and a['block_size'] > 0 and (not sparsity or (a['sparsity_mode'] == 'structured' and 0 < a['N'] <= a['M'])))
+        self._groups = None
+        if lean:
+            nm = sparsity and a['N'] < a['M']
+            f = _fast_quant(a['block_size'], a['mant_bits'], a['epsilon'], a['N'] if nm else 0, a['M'] if nm else 0, a['first'] == 's')
+            groups = {}
+            for i, t in enumerate(self.tensors):
+                native.require_device_tensor(t)
+                groups.setdefault((t.device, t.dtype), []).append(i)
+            self._groups = [(idx, f.prepare([self.tensors[i] for i in idx])) for idx in groups.values()]
+
+    def run(self):
+        out = [None] * len(self.tensors)
+        if self._groups is None:
+            return [float_to_bfp_blocked(t, **self._args, identifier=self._ident) for t in self.tensors]
+        for idx, prep in self._groups:
+            for i, y in zip(idx, prep.run()):
+                out[i] = y.view(self.tensors[i].shape)
+        return out
+
+
 def sparsify(t, sparsity_mode, N=0, M=0, sparsity_frac=0):
     """public alias of _sparsify with sparsity=True"""
     return _sparsify(t, True, sparsity_mode, str(t.device), N, M, sparsity_frac)
@@ -357,6 +414,9 @@ def _get_op_name(name, epsilon, mant_bits, rounding_mode, **kwargs):
     return '%s_BFP_%s_%d' % (name, rounding_mode, mant_bits)
 
 
+FUSE_OPERAND_PAIR = True           # BFPLinear / BFPConv2d forward: quantize activation and weight in one launch when possible
+
+
 _CACHE_KEYS = ('mant_bits', 'epsilon', 'rounding_mode', 'block_size', 'num_format', 'weight_mant_bits', 'w_sparsity',
                'sparsity_frac', 'N', 'M', 'sparsity_num_format', 'first', 'sparsity_mode')
 
@@ -412,9 +472,30 @@ class WeightCache:
         self.value = None
 
 
+def _pair_in_one_launch(x, w, bfp_args):
+    """activation + weight of one Linear through ONE launch (native.FastQuant.many) when both take the drop-in kernel with
+    the same plan: 'bfp' format, round-half-even, dense or structured pruning per operand; else None"""
+    a = bfp_args
+    if (a['sparsity_num_format'] != 'bfp' or a['rounding_mode'] != rounding_modes.DETERM or a['num_format'] != 'bfp'
+            or x.dtype != w.dtype or x.device != w.device or x.device.type != 'cuda' or torch.compiler.is_compiling()):
+        return None
+    sp_in, sp_w = a['in_sparsity'] == True, a['w_sparsity'] == True  # noqa: E712
+    if (sp_in or sp_w):
+        if a['sparsity_mode'] != 'structured' or not (0 < a['N'] <= a['M']):
+            return None
+    nm = (sp_in or sp_w) and a['N'] < a['M']
+    f = _fast_quant(a['block_size'], a['mant_bits'], a['epsilon'], a['N'] if nm else 0, a['M'] if nm else 0, a['first'] == 's')
+    xq, wq = f.many([x, w], [sp_in, sp_w])
+    return xq.view(x.shape), wq.view(w.shape)
+
+
 def _quantize_operands(x, w, transpose, bfp_args, cache):
     """(Q_in(x), Q_w(w)) -- reference MxM_pre_processing (bfp_ops.py:151-155), with the optional weight cache"""
-    if cache is None:
+    if cache is None or not cache.usable(w, bfp_args):
+        if transpose != True and FUSE_OPERAND_PAIR:  # noqa: E712
+            pair = _pair_in_one_launch(x, w, bfp_args)
+            if pair is not None:
+                return pair
         return MxM_pre_processing(x, w, transpose, **bfp_args)
     xq = float_to_bfp_blocked(x, **bfp_args, identifier='in')
     wq = cache.lookup(w, bfp_args)

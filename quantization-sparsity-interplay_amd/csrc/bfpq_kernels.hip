@@ -110,8 +110,16 @@ __device__ __forceinline__ Hot16 hot16_scale(uint32_t max_key, const FusedArgs& 
 //   wider than the dtype) makes the whole wavefront replay that item through the step-by-step
 //   emulation (quant_elem); the branch is wave-uniform and never taken on ordinary weights.
 // ---------------------------------------------------------------------------------------------
-template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY>
-__global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
+// A list of tensors in one launch (bfpq_fake_quantize_batched): up to kMaxBatch descriptors travel in the kernel arguments
+// (no device memory, graph-capturable).  The tensors share dtype / block / mantissa width; each is a flat array of lane
+// items cut into chunks of 256 (the last chunk of a tensor is ragged), the chunks of all tensors form one index space
+// that the workgroups stride over.  flags bit 0: apply the N:M mask to this tensor (a Linear's weight) or not (its activation).
+constexpr int kMaxBatch = 64;
+struct BatchDesc { const void* in; void* out; int64_t n_items; uint32_t chunk0; uint32_t flags; };
+struct BatchArgs { int n; uint32_t total_chunks; BatchDesc d[kMaxBatch]; };
+
+template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY, bool BATCHED>
+__device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unused]] const BatchArgs* b)
 {
     using T = Traits<DT>;
     constexpr int VEC = T::VEC;
@@ -302,9 +310,13 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
     // One lane item.  GUARD = false in the main loop (every lane of the grid holds a real item: no
     // branch around any memory operation, so hipcc can emit counted vmcnt waits and keep the prefetches
     // and the previous store in flight); GUARD = true only in the ragged last sweep.
+    // (batched mode: the tensor's own output pointer, item count and N:M switch; else the launch's)
+    void* out_deq = a.out_deq;
+    int64_t n_limit = a.n_items;
+    [[maybe_unused]] bool nm_on = true;
     auto body = [&](auto guard_tag, const int64_t item, const uint4 cur) __attribute__((always_inline)) {
         constexpr bool GUARD = decltype(guard_tag)::value;
-        const bool valid = !GUARD || item < a.n_items;
+        const bool valid = !GUARD || item < n_limit;
         item_valid = valid;
         item_index = item;
         uint32_t d0 = cur.x, d1 = cur.y, d2 = cur.z, d3 = cur.w;
@@ -313,7 +325,10 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
         if (valid && a.out_deq) stream_store(reinterpret_cast<uint4*>(a.out_deq) + item, make_uint4(d0, d1, d2, d3));
         return;
 #endif
-        if constexpr (NM != 0 && SFIRST) nm_mask(d0, d1, d2, d3);             // S before Q (bfp_ops.py:141-144)
+        if constexpr (NM != 0 && SFIRST) {                                     // S before Q (bfp_ops.py:141-144)
+            if constexpr (BATCHED) { if (nm_on) nm_mask(d0, d1, d2, d3); }
+            else nm_mask(d0, d1, d2, d3);
+        }
 
         uint32_t o0 = d0, o1 = d1, o2 = d2, o3 = d3;
         float code[VEC];
@@ -425,7 +440,8 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
             }
         }
         if constexpr (NM != 0 && !SFIRST) {                                   // Q before S (bfp_ops.py:146-149)
-            nm_mask(o0, o1, o2, o3);
+            if constexpr (BATCHED) { if (nm_on) nm_mask(o0, o1, o2, o3); }
+            else nm_mask(o0, o1, o2, o3);
             if (a.out_codes) {                                                // a pruned element has code 0
                 if constexpr (VEC == 4) {
                     code[0] = (o0 & T::ABS) ? code[0] : 0.f; code[1] = (o1 & T::ABS) ? code[1] : 0.f;
@@ -438,7 +454,7 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
             }
         }
         if constexpr (DEQ_ONLY) {                                           // hot mode: exactly one store per item
-            if (valid) stream_store(reinterpret_cast<uint4*>(a.out_deq) + item, make_uint4(o0, o1, o2, o3));
+            if (valid) stream_store(reinterpret_cast<uint4*>(out_deq) + item, make_uint4(o0, o1, o2, o3));
             return;
         }
         if (!valid) return;
@@ -485,14 +501,79 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
         }
     };
 
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    auto u4 = [](const u4v v) __attribute__((always_inline)) { return make_uint4(v.x, v.y, v.z, v.w); };
+    if constexpr (BATCHED) {
+        // chunk c of the list = chunk (c - chunk0[t]) of tensor t; a workgroup's chunks only move forward, so t does too
+        __shared__ uint32_t s_chunk0[kMaxBatch + 1];
+        if ((int)threadIdx.x <= b->n) s_chunk0[threadIdx.x] = (int)threadIdx.x < b->n ? b->d[threadIdx.x].chunk0 : b->total_chunks;
+        __syncthreads();
+        struct Cur { const uint4* in; void* out; int64_t n; int64_t item; bool nm; };
+        // the descriptor of the current tensor is re-read (scalar loads from the kernel arguments) only when a chunk
+        // crosses into another tensor: the address of the next load must not wait for a descriptor load every sweep
+        int t = 0;
+        const uint4* d_in = reinterpret_cast<const uint4*>(b->d[0].in);
+        void* d_out = b->d[0].out;
+        int64_t d_n = b->d[0].n_items;
+        uint32_t d_c0 = b->d[0].chunk0, d_c1 = b->n > 1 ? b->d[1].chunk0 : b->total_chunks;
+        bool d_nm = (b->d[0].flags & 1u) != 0;
+        auto locate = [&](uint32_t c) __attribute__((always_inline)) {
+            if (c >= d_c1) {                                   // (wave-uniform: c depends on blockIdx only)
+                while (t + 1 < b->n && c >= s_chunk0[t + 1]) t++;
+                t = __builtin_amdgcn_readfirstlane(t);
+                const BatchDesc& d = b->d[t];
+                d_in = reinterpret_cast<const uint4*>(d.in); d_out = d.out; d_n = d.n_items; d_nm = (d.flags & 1u) != 0;
+                d_c0 = d.chunk0; d_c1 = s_chunk0[t + 1];
+            }
+            Cur r;
+            r.in = d_in; r.out = d_out; r.n = d_n; r.nm = d_nm;
+            r.item = (int64_t)(c - d_c0) * kThreads + threadIdx.x;
+            return r;
+        };
+        auto fetchb = [&](const Cur& r) __attribute__((always_inline)) {     // (every chunk of a batched tensor is full: no clamp)
+            return __builtin_nontemporal_load(reinterpret_cast<const u4v*>(r.in + r.item));
+        };
+        auto use = [&](const Cur& r) __attribute__((always_inline)) { out_deq = r.out; n_limit = r.n; nm_on = r.nm; };
+        const uint32_t total = b->total_chunks, last_c = total - 1, G = gridDim.x;
+        uint32_t cc = blockIdx.x;
+        Cur cA = locate(cc < total ? cc : last_c);             // (more workgroups than chunks: they load the last chunk, store nothing)
+        u4v vA = fetchb(cA);
+        // (the tables are filled by the code below in the flat mode; here, behind the first load as well)
+        {
+            const int tt = threadIdx.x;
+            for (int i = tt; i < 512; i += kThreads) s_win[i] = (a.exp_win && i < BFPQ_EXP_WIN_ENTRIES) ? a.exp_win[i] : 0;
+            if constexpr (NM == 4) {
+                for (int i = tt; i < BFPQ_NM4_LUT_ENTRIES; i += kThreads) {
+                    const uint32_t k = a.nm_lut[i];
+                    if constexpr (VEC == 8)
+                        s_mask[i] = make_uint2(((k & 1u) ? 0xffffu : 0u) | ((k & 2u) ? 0xffff0000u : 0u),
+                                               ((k & 4u) ? 0xffffu : 0u) | ((k & 8u) ? 0xffff0000u : 0u));
+                    else s_keep[i] = (uint8_t)k;
+                }
+            }
+        }
+        __syncthreads();
+        // two chunks per trip, register sets alternating by name (as the flat sweep below), bodies unguarded
+        for (; cc < total && cc + G < total; cc += 2 * G) {
+            const Cur cB = locate(cc + G);
+            const u4v vB = fetchb(cB);
+            use(cA);
+            body(std::false_type{}, cA.item, u4(vA));
+            const uint32_t c3 = cc + 2 * G < total ? cc + 2 * G : last_c;
+            cA = locate(c3);
+            vA = fetchb(cA);
+            use(cB);
+            body(std::false_type{}, cB.item, u4(vB));
+        }
+        if (cc < total) { use(cA); body(std::false_type{}, cA.item, u4(vA)); }
+        return;
+    }
     // Sweep: item = sweep * stride + global thread id.  Loads run two sweeps ahead of the item being
     // processed (index clamped to the last item, never conditional).
     const int64_t last = a.n_items - 1;
-    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
     auto fetch = [&](int64_t i) __attribute__((always_inline)) {
         return __builtin_nontemporal_load(reinterpret_cast<const u4v*>(src + (i < last ? i : last)));
     };
-    auto u4 = [](const u4v v) __attribute__((always_inline)) { return make_uint4(v.x, v.y, v.z, v.w); };
     const int64_t full = a.n_items / stride;                               // sweeps in which every thread has an item
     int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     u4v c0 = fetch(item);
@@ -561,6 +642,30 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
         c0 = c1;
     }
     asm volatile("" : : "v"(dummy));                                       // the dummy's only "use": after all the work
+}
+
+template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY>
+__global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
+{
+    fused_flat_body<DT, NM, SFIRST, STOCH, LPBT, DEQ_ONLY, false>(a, nullptr);
+}
+
+// the same item pipeline over a list of tensors (drop-in mode, round-half-even, dense or N:4)
+template <int DT, int NM, bool SFIRST, int LPBT>
+__global__ void __launch_bounds__(kThreads) k_fused_batched(const FusedArgs a, const BatchArgs b)
+{
+    // The descriptor list is indexed with a run-time (wave-uniform) index.  Taking the address of the by-value parameter
+    // would make hipcc copy all 2 KB of it into per-lane scratch; reading it where it already lies -- in the kernel
+    // argument segment, explicit arguments in order at their natural alignment -- keeps the accesses scalar loads.
+    constexpr size_t kOff = (sizeof(FusedArgs) + alignof(BatchArgs) - 1) / alignof(BatchArgs) * alignof(BatchArgs);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const BatchArgs* bp = (const BatchArgs*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + kOff);
+#else
+    const BatchArgs* bp = &b;
+    (void)kOff;
+#endif
+    (void)b;
+    fused_flat_body<DT, NM, SFIRST, false, LPBT, true, true>(a, bp);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1012,6 +1117,23 @@ bool fused_shape_ok(int64_t rows, int64_t cols, int dtype, int block_size, int N
     return is_pow2(lpb) && lpb <= 64;
 }
 
+template <int DT, int NM, bool SFIRST>
+int launch_batched(const FusedArgs& a, const BatchArgs& b, hipStream_t s)
+{
+    const dim3 grid(grid_for((int64_t)b.total_chunks * kThreads)), block(kThreads);
+    if (a.lpb == 4) hipLaunchKernelGGL((k_fused_batched<DT, NM, SFIRST, 4>), grid, block, 0, s, a, b);
+    else if (a.lpb == 8) hipLaunchKernelGGL((k_fused_batched<DT, NM, SFIRST, 8>), grid, block, 0, s, a, b);
+    else hipLaunchKernelGGL((k_fused_batched<DT, NM, SFIRST, -1>), grid, block, 0, s, a, b);
+    return (int)hipGetLastError();
+}
+
+template <int DT>
+int launch_batched_dt(const FusedArgs& a, const BatchArgs& b, int M, bool sfirst, hipStream_t s)
+{
+    if (M == 0) return launch_batched<DT, 0, true>(a, b, s);
+    return sfirst ? launch_batched<DT, 4, true>(a, b, s) : launch_batched<DT, 4, false>(a, b, s);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1194,6 +1316,66 @@ int bfpq_fake_quantize(const bfpq_plan* p, const void* in, void* out, int64_t ro
     if (!p) return BFPQ_E_ARG;
     return bfpq_quantize_nm(in, out, nullptr, nullptr, rows, cols, p->dtype, p->block_size, p->mant_bits, p->epsilon, p->N, p->M,
                             p->sparsify_first, 0, 0, p->exp_win_dev, p->nm_lut_dev, nullptr, stream);
+}
+
+int bfpq_fake_quantize_batched(const bfpq_plan* p, const bfpq_tensor_desc* descs, int n, void* stream)
+{
+    if (!p || (n > 0 && !descs) || n < 0) return BFPQ_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int dtype = p->dtype;
+    if (dtype < 0 || dtype > 2 || p->block_size < 0 || (p->block_size > 0 && !p->exp_win_dev)) return BFPQ_E_ARG;
+    const bool any_nm_cfg = p->M > 0;
+    // tensors the single-pass kernel takes go into launches of up to kMaxBatch; the rest (ragged shapes, N:8, ...) one by one
+    BatchArgs b;
+    b.n = 0; b.total_chunks = 0;
+    FusedArgs a;
+    a.in = nullptr; a.out_deq = nullptr; a.out_codes = nullptr; a.out_exp = nullptr; a.n_items = 0;
+    a.exp_win = p->exp_win_dev; a.nm_lut = p->nm_lut_dev; a.seed = 0; a.eps_dt = h_round((float)p->epsilon, dtype);
+    a.lpb = p->block_size ? p->block_size / dtype_vec(dtype) : 0;
+    a.mant_bits = p->mant_bits; a.N = p->N; a.code_bits = 0;
+    a.force_slow = p->mant_bits > (dtype == BFPQ_F32 ? 24 : (dtype == BFPQ_F16 ? 11 : 8));
+    set_hot16(a, dtype, p->mant_bits, a.eps_dt);
+    a.selws = nullptr;
+    bool batch_has_nm = false;
+    auto flush = [&]() -> int {
+        if (b.n == 0) return 0;
+        const int M = batch_has_nm ? 4 : 0;
+        int rc;
+        if (dtype == BFPQ_F32) rc = launch_batched_dt<BFPQ_F32>(a, b, M, p->sparsify_first != 0, s);
+        else if (dtype == BFPQ_F16) rc = launch_batched_dt<BFPQ_F16>(a, b, M, p->sparsify_first != 0, s);
+        else rc = launch_batched_dt<BFPQ_BF16>(a, b, M, p->sparsify_first != 0, s);
+        b.n = 0; b.total_chunks = 0; batch_has_nm = false;
+        return rc;
+    };
+    for (int i = 0; i < n; i++) {
+        const bfpq_tensor_desc& d = descs[i];
+        if (d.rows < 0 || d.cols < 0) return BFPQ_E_ARG;
+        if (d.rows * d.cols == 0) continue;
+        if (!d.in_dev || !d.out_dev) return BFPQ_E_ARG;
+        const bool nm = any_nm_cfg && d.apply_nm != 0;
+        const int N = nm ? p->N : 0, M = nm ? p->M : 0;
+        if (p->block_size == 0 && M == 0) return BFPQ_E_ARG;                // identity: the caller keeps its tensor
+        const bool aligned = ((reinterpret_cast<uintptr_t>(d.in_dev) | reinterpret_cast<uintptr_t>(d.out_dev)) & 15u) == 0;
+        const bool ok = aligned && (M == 0 || (M == 4 && p->nm_lut_dev)) && p->block_size > 0 &&
+                        fused_shape_ok(d.rows, d.cols, dtype, p->block_size, N, M) &&
+                        (d.rows * d.cols / dtype_vec(dtype)) % kThreads == 0 &&          // whole chunks of 256 lane items only
+
+                        (d.rows * d.cols / dtype_vec(dtype) + kThreads - 1) / kThreads < ((int64_t)1 << 31);
+        if (!ok) {
+            const int rc = bfpq_quantize_nm(d.in_dev, d.out_dev, nullptr, nullptr, d.rows, d.cols, dtype, p->block_size, p->mant_bits, p->epsilon,
+                                            N, M, p->sparsify_first, 0, 0, p->exp_win_dev, p->nm_lut_dev, nullptr, stream);
+            if (rc) return rc;
+            continue;
+        }
+        const int64_t items = d.rows * d.cols / dtype_vec(dtype);
+        const int64_t chunks = (items + kThreads - 1) / kThreads;
+        if (b.n == kMaxBatch || (int64_t)b.total_chunks + chunks >= ((int64_t)1 << 32)) { const int rc = flush(); if (rc) return rc; }
+        BatchDesc& o = b.d[b.n++];
+        o.in = d.in_dev; o.out = d.out_dev; o.n_items = items; o.chunk0 = b.total_chunks; o.flags = nm ? 1u : 0u;
+        b.total_chunks += (uint32_t)chunks;
+        batch_has_nm = batch_has_nm || nm;
+    }
+    return flush();
 }
 
 int bfpq_nm_sparsify(const void* in, void* out, int64_t rows, int64_t cols, int dtype, int N, int M,

@@ -74,6 +74,7 @@ def load_library():
         L.bfpq_nm_prune_mask_host.restype = u64
         L.bfpq_quantize_nm.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, dbl, i32, i32, i32, i32, u64, vp, vp, vp, vp]
         L.bfpq_fake_quantize.argtypes = [vp, vp, vp, i64, i64, vp]
+        L.bfpq_fake_quantize_batched.argtypes = [vp, vp, i32, vp]
         L.bfpq_is_fused.argtypes = [i64, i64, i32, i32, i32, i32]
         L.bfpq_nm_sparsify.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp]
         L.bfpq_select_passes.argtypes = [i32]
@@ -92,7 +93,7 @@ def load_library():
         L.bfpq_hbfp_linear_decode.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
         L.bfpq_hbfp_linear_tiled_ok.argtypes = [i64, i64]
         L.bfpq_hbfp_linear_decode_tiled.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
-        for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_is_fused", "bfpq_nm_sparsify",
+        for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_is_fused", "bfpq_nm_sparsify",
                      "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
                      "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize", "bfpq_hbfp_linear_slices",
                      "bfpq_hbfp_linear_decode", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled"):
@@ -102,7 +103,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_select_ws_bytes", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24",
-                    "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_is_fused", "bfpq_nm_sparsify",
+                    "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_is_fused", "bfpq_nm_sparsify",
                     "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
                     "bfpq_threshold_apply", "bfpq_quantize_threshold")
 
@@ -241,6 +242,12 @@ class _Plan(ctypes.Structure):
                 ("exp_win_dev", ctypes.c_void_p), ("nm_lut_dev", ctypes.c_void_p)]
 
 
+class _TensorDesc(ctypes.Structure):
+    """include/bfpq.h: bfpq_tensor_desc"""
+    _fields_ = [("in_dev", ctypes.c_void_p), ("out_dev", ctypes.c_void_p), ("rows", ctypes.c_int64), ("cols", ctypes.c_int64),
+                ("apply_nm", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
@@ -291,6 +298,104 @@ class FastQuant:
         if rc:
             check(rc, "bfpq_fake_quantize")
         return dst
+
+    def prepare(self, tensors, apply_nm=None, outs=None):
+        """PreparedList for these tensors: outputs allocated and descriptors built once, .run() re-issues the launches.
+        For tensors whose storage stays put (the weights of a model quantized every forward)."""
+        return PreparedList(self, tensors, apply_nm, outs)
+
+    def many(self, tensors, apply_nm=None, outs=None):
+        """the same for a LIST of tensors of one dtype on one device, in as few launches as possible
+        (bfpq_fake_quantize_batched: up to 64 tensors per launch).  apply_nm: per tensor, whether this plan's N:M pruning
+        applies to it (default: to all).  Returns the list of results (a tensor the plan leaves untouched comes back itself)."""
+        n = len(tensors)
+        if n == 0:
+            return []
+        flags = [True] * n if apply_nm is None else [bool(f) for f in apply_nm]
+        t0 = tensors[0]
+        require_device_tensor(t0)
+        dev, dt = t0.device, t0.dtype
+        res = [None] * n
+        descs = (_TensorDesc * n)()
+        keep = []                                              # contiguous copies live until the call returns (stream-ordered after that)
+        k = 0
+        for i, t in enumerate(tensors):
+            if t.device != dev or t.dtype != dt:
+                raise ValueError("FastQuant.many: the tensors of one call share device and dtype")
+            if self.block_size == 0 and not (flags[i] and self.M > 0):
+                res[i] = t                                     # identity for this tensor
+                continue
+            src = t if t.is_contiguous() else t.contiguous()
+            dst = torch.empty_like(src) if outs is None or outs[i] is None else outs[i]
+            res[i] = dst
+            if src.numel() == 0:
+                continue
+            cols = src.shape[-1] if src.dim() else 1
+            d = descs[k]
+            d.in_dev, d.out_dev, d.rows, d.cols, d.apply_nm = src.data_ptr(), dst.data_ptr(), src.numel() // cols, cols, 1 if flags[i] else 0
+            res[i] = dst
+            k += 1
+            keep.append(src)
+        if k:
+            plan = self._plan(dt, dev)
+            with torch.cuda.device(dev):
+                rc = load_library().bfpq_fake_quantize_batched(plan[1], ctypes.addressof(descs), k, torch.cuda.current_stream(dev).cuda_stream)
+            if rc:
+                check(rc, "bfpq_fake_quantize_batched")
+        return res
+
+
+class PreparedList:
+    """A list of tensors bound to one FastQuant plan: input pointers, output tensors and the descriptor array are set up
+    once; run() is ONE ctypes call (bfpq_fake_quantize_batched) whatever the number of tensors.  The inputs must keep their
+    storage (and stay contiguous) between runs; results are written in place into .outputs."""
+
+    def __init__(self, fq, tensors, apply_nm=None, outs=None):
+        tensors = list(tensors)
+        n = len(tensors)
+        flags = [True] * n if apply_nm is None else [bool(f) for f in apply_nm]
+        self.fq = fq
+        self.outputs = [None] * n
+        self._keep = []
+        self._descs = (_TensorDesc * max(n, 1))()
+        self._k = 0
+        self.device = self.dtype = None
+        for i, t in enumerate(tensors):
+            require_device_tensor(t)
+            if self.device is None:
+                self.device, self.dtype = t.device, t.dtype
+            if t.device != self.device or t.dtype != self.dtype:
+                raise ValueError("PreparedList: the tensors of one list share device and dtype")
+            if not t.is_contiguous():
+                raise ValueError("PreparedList needs contiguous inputs (their storage is bound)")
+            if fq.block_size == 0 and not (flags[i] and fq.M > 0):
+                self.outputs[i] = t
+                continue
+            dst = torch.empty_like(t) if outs is None or outs[i] is None else outs[i]
+            self.outputs[i] = dst
+            if t.numel() == 0:
+                continue
+            cols = t.shape[-1] if t.dim() else 1
+            d = self._descs[self._k]
+            d.in_dev, d.out_dev, d.rows, d.cols, d.apply_nm = t.data_ptr(), dst.data_ptr(), t.numel() // cols, cols, 1 if flags[i] else 0
+            self._k += 1
+            self._keep.append(t)
+        self._plan = fq._plan(self.dtype, self.device) if self._k else None
+        self._fn = load_library().bfpq_fake_quantize_batched
+        self._addr = ctypes.addressof(self._descs)
+
+    def run(self):
+        if self._k:
+            dev = self.device
+            if torch.cuda.current_device() != dev.index:
+                with torch.cuda.device(dev):
+                    rc = self._fn(self._plan[1], self._addr, self._k, torch.cuda.current_stream(dev).cuda_stream)
+            else:
+                rc = self._fn(self._plan[1], self._addr, self._k,
+                              _raw_stream(dev.index) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream)
+            if rc:
+                check(rc, "bfpq_fake_quantize_batched")
+        return self.outputs
 
 
 class SelectWorkspace:

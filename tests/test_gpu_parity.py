@@ -895,3 +895,54 @@ def test_every_block_max_pattern_dropin(dname):
         assert_bits_equal(bits(got), bits(want), dt, f"{dname} m={m} eps={eps}")
     got = bfp_ops._no_sparsity_float_to_bfp(x.view(-1, 16), 16, 3, 1e-8, 'determ', 'cuda')          # other lane-group widths
     assert_bits_equal(bits(got), bits(O.no_sparsity_float_to_bfp(xc.view(-1, 16), 16, 3, 1e-8)), dt, f"{dname} block 16")
+
+
+@pytest.mark.parametrize("dname", ["bf16", "f16", "f32"])
+def test_batched_list_equals_per_tensor_and_oracle(dname):
+    """bfpq_fake_quantize_batched (a list of tensors per launch) == the per-tensor call == the oracle: mixed shapes incl.
+    ragged ones (handled one by one inside the call), an empty tensor, more than 64 tensors (two launches), 3-D inputs,
+    and the N:M switch per tensor (a Linear's activation next to its weight)."""
+    dt = DT[dname]
+    shapes = [(64, 256), (3, 64), (257, 1024), (5, 100), (0, 128), (2, 7, 128), (768, 768), (33, 192)] + [(4 + i, 64 * (1 + i % 3)) for i in range(66)]
+    xs_c = [synth(int(np.prod(sh[:-1])), sh[-1], dt, 0.5, seed=10 + i).view(sh) for i, sh in enumerate(shapes)]
+    xs = [x.to(DEV) for x in xs_c]
+    for c in (cfg(w_sparsity=True), cfg(w_sparsity=True, first='q', mant_bits=7, block_size=32), cfg()):
+        got = bfp_ops.float_to_bfp_blocked_many(xs, identifier='w', **c)
+        assert len(got) == len(xs)
+        for i, (g, x, xc) in enumerate(zip(got, xs, xs_c)):
+            assert g.shape == x.shape and g.dtype == dt
+            assert_bits_equal(bits(g), bits(bfp_ops.float_to_bfp_blocked(x, **c, identifier='w')), dt, f"batched vs single #{i} {tuple(x.shape)}")
+            if i < 8:
+                assert_bits_equal(bits(g), bits(O.float_to_bfp_blocked(xc, **c, identifier='w')), dt, f"batched vs oracle #{i} {tuple(x.shape)}")
+    # per-tensor N:M switch: activation dense, weight 2:4 -- what one BFPLinear forward issues
+    f = native.FastQuant(64, 3, 1e-8, 2, 4, True)
+    a, w = xs[2], xs[0]
+    qa, qw = f.many([a, w], [False, True])
+    assert_bits_equal(bits(qa), bits(O.float_to_bfp_blocked(xs_c[2], **cfg(), identifier='in')), dt, "pair: activation")
+    assert_bits_equal(bits(qw), bits(O.float_to_bfp_blocked(xs_c[0], **cfg(w_sparsity=True), identifier='w')), dt, "pair: weight")
+    lin = bfp_ops.BFPLinear(256, 64, True, **cfg(w_sparsity=True)).to(DEV).to(dt)
+    x = synth(10, 256, dt, 1.0).to(DEV)
+    with torch.no_grad():
+        y = lin(x)
+        bfp_ops.FUSE_OPERAND_PAIR = False
+        try:
+            y2 = lin(x)
+        finally:
+            bfp_ops.FUSE_OPERAND_PAIR = True
+    assert torch.equal(y, y2)
+
+
+def test_prepared_list_reruns_in_place():
+    """PreparedMany: descriptors and outputs bound once; run() after an in-place weight update gives the new results"""
+    ws = [synth(64 + 8 * i, 256, torch.bfloat16, 0.5, seed=i).to(DEV) for i in range(5)]
+    c = cfg(w_sparsity=True)
+    prep = bfp_ops.PreparedMany(ws, identifier='w', **c)
+    a = [y.clone() for y in prep.run()]
+    for w, y in zip(ws, a):
+        assert torch.equal(y, bfp_ops.float_to_bfp_blocked(w, **c, identifier='w'))
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.7)
+    b = prep.run()
+    for w, y in zip(ws, b):
+        assert torch.equal(y, bfp_ops.float_to_bfp_blocked(w, **c, identifier='w'))

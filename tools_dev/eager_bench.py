@@ -83,7 +83,7 @@ def main():
     for name, fin, fout, tokens, cache in (("BFPLinear down_proj 1 token (reference semantics)", 11008, 4096, 1, False),
                                            ("BFPLinear down_proj 1 token (weight cache)", 11008, 4096, 1, True),
                                            ("BFPLinear q_proj 16 tokens (weight cache)", 4096, 4096, 16, True)):
-        lin = bfp_ops.BFPLinear(fin, fout, bias=False, **cfg(device='cuda')).to(DEV).to(torch.bfloat16)
+        lin = bfp_ops.BFPLinear(fin, fout, bias=False, **cfg(device="cuda")).to(DEV).to(torch.bfloat16).eval()
         if cache:
             lin.enable_weight_cache()
         x = torch.randn(tokens, fin, device=DEV, dtype=torch.bfloat16)
