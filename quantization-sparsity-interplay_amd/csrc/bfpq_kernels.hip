@@ -869,6 +869,112 @@ __global__ void __launch_bounds__(kThreads) k_quant_rows(const void* in, void* o
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_quant_rows_tiled: drop-in HBFP quantizer for rows whose length is a multiple of the vector width but NOT of the
+// block (the reference's per-row F.pad, bfp_ops.py:50-53), block = a power-of-two number of lane items.  A workgroup
+// walks whole rows (no division anywhere), its waves the 64-item tiles of the row; lanes past the end of the row hold the
+// pad zeros.  Same three tiers of arithmetic as the flat kernel (lean 16-bit path / exact power-of-two path / step replay).
+// ---------------------------------------------------------------------------------------------
+template <int DT>
+__global__ void __launch_bounds__(kThreads) k_quant_rows_tiled(const FusedArgs a, int64_t rows, int64_t ipr)
+{
+    using T = Traits<DT>;
+    constexpr int VEC = T::VEC;
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[512];
+    for (int i = threadIdx.x; i < 512; i += kThreads) s_win[i] = i < BFPQ_EXP_WIN_ENTRIES ? a.exp_win[i] : 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t tpr = (ipr + 63) / 64;                          // tiles per row
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(a.in);
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(a.out_deq);
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    // (row, tile) of this wave, advanced tile by tile; the next tile's load is issued before the current one is processed
+    int64_t row = blockIdx.x, tile = w;
+    auto advance = [&](int64_t& r, int64_t& t) __attribute__((always_inline)) {
+        t += kThreads / 64;
+        if (t >= tpr) { t = w; r += gridDim.x; }
+    };
+    auto fetch = [&](int64_t r, int64_t t) __attribute__((always_inline)) {     // lanes past the end of the row hold the pad zeros
+        const int64_t it = t * 64 + lane;
+        u4v v = {0u, 0u, 0u, 0u};
+        if (r < rows && it < ipr) v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(src + r * ipr + it));
+        return v;
+    };
+    if (tile >= tpr) { tile = w; row = rows; }                    // (more waves than tiles in a row: idle wave)
+    u4v cur = fetch(row, tile);
+    // (measured: an unconditional clamped load + two tiles per trip, as in the flat kernel, is SLOWER here: 41.4 vs 38.6 us)
+    while (row < rows) {
+        int64_t nrow = row, ntile = tile;
+        advance(nrow, ntile);
+        const u4v nxt = fetch(nrow, ntile);
+        const u4v c = cur;
+        const int64_t it = tile * 64 + lane;
+        const bool valid = it < ipr;
+        uint32_t d0 = c.x, d1 = c.y, d2 = c.z, d3 = c.w, o0, o1, o2, o3;
+        uint32_t mx;
+        if constexpr (VEC == 8) {
+            const uint32_t absm = T::ABS | (T::ABS << 16);
+            const uint32_t mp = pk_max_u16(pk_max_u16(d0 & absm, d1 & absm), pk_max_u16(d2 & absm, d3 & absm));
+            mx = (mp & 0xffffu) > (mp >> 16) ? (mp & 0xffffu) : (mp >> 16);
+        } else {
+            const uint32_t m01 = (d0 & T::ABS) > (d1 & T::ABS) ? (d0 & T::ABS) : (d1 & T::ABS);
+            const uint32_t m23 = (d2 & T::ABS) > (d3 & T::ABS) ? (d2 & T::ABS) : (d3 & T::ABS);
+            mx = m01 > m23 ? m01 : m23;
+        }
+        mx = group_max<-1>(mx, a.lpb);
+        bool hot = false;
+        [[maybe_unused]] Hot16 h16;
+        if constexpr (VEC == 8) { h16 = hot16_scale<DT>(mx, a, s_win); hot = !__any(!h16.ok); }
+        if (hot) {
+            if constexpr (VEC == 8) {
+                const uint32_t absm = T::ABS | (T::ABS << 16);
+                const uint32_t dd[4] = {d0, d1, d2, d3};
+                uint32_t oo[4];
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    const uint32_t am = pk_min_u16(dd[x] & absm, h16.maxv2);
+                    typedef float float2v __attribute__((ext_vector_type(2)));
+                    const float2v C2 = {h16.C, h16.C};
+                    float2v v;
+                    if constexpr (DT == BFPQ_BF16) v = (float2v){u2f(am << 16), u2f(am & 0xffff0000u)} + C2;
+                    else v = (float2v){fma_mix_f16<false>(am, h16.C), fma_mix_f16<true>(am, h16.C)};
+                    v -= C2;
+                    uint32_t pk;
+                    if constexpr (DT == BFPQ_BF16) pk = __builtin_amdgcn_perm(f2u(v.y), f2u(v.x), 0x07060302u);
+                    else pk = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
+                    oo[x] = bfi_b32(absm, pk, dd[x]);
+                }
+                o0 = oo[0]; o1 = oo[1]; o2 = oo[2]; o3 = oo[3];
+            }
+        } else {
+            uint32_t raw[VEC], outraw[VEC];
+            if constexpr (VEC == 4) { raw[0] = d0; raw[1] = d1; raw[2] = d2; raw[3] = d3; }
+            else {
+                raw[0] = d0 & 0xffffu; raw[1] = d0 >> 16; raw[2] = d1 & 0xffffu; raw[3] = d1 >> 16;
+                raw[4] = d2 & 0xffffu; raw[5] = d2 >> 16; raw[6] = d3 & 0xffffu; raw[7] = d3 >> 16;
+            }
+            const FastScale fs = fast_scale<DT>(mx, a.mant_bits, a.eps_dt, s_win);
+            if (__any(a.force_slow != 0 || !fs.ok)) {
+                const BlockScale bs = block_scale<DT>(mx, a.mant_bits, a.eps_dt, s_win);
+                float code;
+#pragma unroll
+                for (int j = 0; j < VEC; j++) outraw[j] = f32_to_raw<DT>(quant_elem<DT>(raw_to_f32<DT>(raw[j]), bs, false, 0.f, &code));
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; j++)
+                    outraw[j] = f32_to_raw<DT>(__builtin_amdgcn_fmed3f(rintf(raw_to_f32<DT>(raw[j]) * fs.inv), -fs.qmax, fs.qmax) * fs.interval);
+            }
+            if constexpr (VEC == 4) { o0 = outraw[0]; o1 = outraw[1]; o2 = outraw[2]; o3 = outraw[3]; }
+            else {
+                o0 = outraw[0] | (outraw[1] << 16); o1 = outraw[2] | (outraw[3] << 16);
+                o2 = outraw[4] | (outraw[5] << 16); o3 = outraw[6] | (outraw[7] << 16);
+            }
+        }
+        if (valid) stream_store(dst + row * ipr + it, make_uint4(o0, o1, o2, o3));
+        row = nrow; tile = ntile; cur = nxt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_quant_rows_vec: HBFP quantizer for rows that are 16-byte aligned (cols % VEC == 0, block % VEC == 0,
 // aligned pointers) but whose length is NOT a multiple of the block, or whose block is not a power-of-two
 // number of lane items.  A block owns GP = pow2ceil(block / VEC) adjacent lanes; lane j of the group holds
@@ -1058,6 +1164,8 @@ int launch_nm_rows(const void* in, void* out, void* codes, int code_bits, int64_
     return (int)hipGetLastError();
 }
 
+void set_hot16(FusedArgs& a, int dtype, int mant_bits, float eps_dt);
+
 int launch_quant_rows(const void* in, void* out_deq, void* out_codes, int8_t* out_exp, int64_t rows, int64_t cols, int dtype,
                       int block, int mant_bits, float eps_dt, int code_bits, uint64_t seed, const uint8_t* exp_win, hipStream_t s)
 {
@@ -1065,6 +1173,21 @@ int launch_quant_rows(const void* in, void* out_deq, void* out_codes, int8_t* ou
     if (total == 0) return 0;
     const int vec = dtype_vec(dtype);
     const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out_deq) | reinterpret_cast<uintptr_t>(out_codes)) & 15u) == 0;
+    if (aligned && out_deq && !out_codes && !out_exp && seed == 0 && cols % vec == 0 && block % vec == 0 && is_pow2(block / vec) && block / vec <= 64) {
+        FusedArgs a;
+        a.in = in; a.out_deq = out_deq; a.out_codes = nullptr; a.out_exp = nullptr; a.n_items = rows * cols / vec;
+        a.exp_win = exp_win; a.nm_lut = nullptr; a.seed = 0; a.eps_dt = eps_dt; a.lpb = block / vec;
+        a.mant_bits = mant_bits; a.N = 0; a.code_bits = 0;
+        a.force_slow = mant_bits > (dtype == BFPQ_F32 ? 24 : (dtype == BFPQ_F16 ? 11 : 8));
+        set_hot16(a, dtype, mant_bits, eps_dt);
+        a.selws = nullptr;
+        const int64_t ipr = cols / vec;
+        const int grid = (int)(rows < 2048 ? rows : 2048);
+        if (dtype == BFPQ_F32) hipLaunchKernelGGL((k_quant_rows_tiled<BFPQ_F32>), dim3(grid), dim3(kThreads), 0, s, a, rows, ipr);
+        else if (dtype == BFPQ_F16) hipLaunchKernelGGL((k_quant_rows_tiled<BFPQ_F16>), dim3(grid), dim3(kThreads), 0, s, a, rows, ipr);
+        else hipLaunchKernelGGL((k_quant_rows_tiled<BFPQ_BF16>), dim3(grid), dim3(kThreads), 0, s, a, rows, ipr);
+        return (int)hipGetLastError();
+    }
     if (aligned && cols % vec == 0 && block % vec == 0 && block / vec <= 64 && (code_bits != 4 || cols % 2 == 0)) {
         int GP = 1;
         while (GP < block / vec) GP <<= 1;
