@@ -45,6 +45,12 @@ template <bool HI> __device__ __forceinline__ float fma_mix_f16(uint32_t a, floa
 }
 
 // scale of a block on the branch-free path; ok == false -> the caller emulates step by step instead
+#ifndef BFPQ_USE_BUF
+#define BFPQ_USE_BUF 0              // A/B knob: drop-in instantiations address the streams through buffer descriptors.  14 VALU
+#endif                              // instructions fewer per item (95 vs 109) and SLOWER: 32.7 vs 31.65 us on one box, interleaved
+#ifndef BFPQ_BUF_DUMMY
+#define BFPQ_BUF_DUMMY 1
+#endif
 struct FastScale { float inv, interval, qmax; int e; bool ok; };
 
 template <int DT>
@@ -314,6 +320,13 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
     void* out_deq = a.out_deq;
     int64_t n_limit = a.n_items;
     [[maybe_unused]] bool nm_on = true;
+    // (A/B knob BFPQ_USE_BUF, off: drop-in instantiations whose arithmetic does not depend on the position of an item address
+    // the two streams through buffer descriptors -- the item offset is ONE 32-bit register advanced by one add per two sweeps,
+    // the look-ahead distance sits in the instruction's scalar offset, out-of-range lanes read zeros / have their stores
+    // dropped by the hardware: no 64-bit index arithmetic, no clamp, no guarded tail; a tensor above 3.9 GB is cut into
+    // several launches by the host.  Measured slower than plain global loads/stores, see the knob.)
+    constexpr bool USE_BUF = BFPQ_USE_BUF && DEQ_ONLY && !STOCH && NM != -1 && !BATCHED;
+    [[maybe_unused]] uint4 buf_res;
     auto body = [&](auto guard_tag, const int64_t item, const uint4 cur) __attribute__((always_inline)) {
         constexpr bool GUARD = decltype(guard_tag)::value;
         const bool valid = !GUARD || item < n_limit;
@@ -453,6 +466,7 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
                 }
             }
         }
+        if constexpr (USE_BUF) { buf_res = make_uint4(o0, o1, o2, o3); return; }   // (the sweep stores it)
         if constexpr (DEQ_ONLY) {                                           // hot mode: exactly one store per item
             if (valid) stream_store(reinterpret_cast<uint4*>(out_deq) + item, make_uint4(o0, o1, o2, o3));
             return;
@@ -566,6 +580,74 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
             body(std::false_type{}, cB.item, u4(vB));
         }
         if (cc < total) { use(cA); body(std::false_type{}, cA.item, u4(vA)); }
+        return;
+    }
+    if constexpr (USE_BUF) {
+        typedef unsigned int v4u __attribute__((vector_size(16)));
+        const uint32_t n_bytes = (uint32_t)(a.n_items * 16);
+        const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.in), 0, (int)n_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(a.out_deq, 0, (int)n_bytes, 0x00020000);
+        const uint32_t sb = (uint32_t)stride * 16u;            // one sweep, in bytes
+        uint32_t voff = ((uint32_t)blockIdx.x * kThreads + threadIdx.x) * 16u;
+        auto bload = [&](uint32_t soff) __attribute__((always_inline)) {
+            const v4u v = __builtin_amdgcn_raw_buffer_load_b128(r_in, (int)voff, (int)soff, 2 /* nt */);
+            return make_uint4(v[0], v[1], v[2], v[3]);
+        };
+        auto bstore = [&](const uint4 o, uint32_t soff) __attribute__((always_inline)) {
+            const v4u v = {o.x, o.y, o.z, o.w};
+            __builtin_amdgcn_raw_buffer_store_b128(v, r_out, (int)voff, (int)soff, 2 /* nt */);
+        };
+        uint4 c0 = bload(0);
+        {
+            // tables -> LDS behind the first tile's load, one dword per thread (see the flat sweep below)
+            const int t = threadIdx.x;
+            const bool win_al = a.exp_win && (reinterpret_cast<uintptr_t>(a.exp_win) & 3u) == 0;
+            const bool lut_al = NM == 4 && (reinterpret_cast<uintptr_t>(a.nm_lut) & 3u) == 0;
+            uint32_t w = 0, k4 = 0;
+            if (win_al && t < BFPQ_EXP_WIN_ENTRIES / 4) w = reinterpret_cast<const uint32_t*>(a.exp_win)[t];
+            if constexpr (NM == 4) {
+                if (lut_al && t < BFPQ_NM4_LUT_ENTRIES / 4) k4 = reinterpret_cast<const uint32_t*>(a.nm_lut)[t];
+                else if (lut_al && t == BFPQ_NM4_LUT_ENTRIES / 4) k4 = a.nm_lut[BFPQ_NM4_LUT_ENTRIES - 1];
+            }
+            if (win_al) { if (t < 128) reinterpret_cast<uint32_t*>(s_win)[t] = w; }
+            else
+                for (int i = t; i < 512; i += kThreads) s_win[i] = (a.exp_win && i < BFPQ_EXP_WIN_ENTRIES) ? a.exp_win[i] : 0;
+            if constexpr (NM == 4) {
+                auto put = [&](int i, uint32_t k) __attribute__((always_inline)) {
+                    if constexpr (VEC == 8)
+                        s_mask[i] = make_uint2(((k & 1u) ? 0xffffu : 0u) | ((k & 2u) ? 0xffff0000u : 0u),
+                                               ((k & 4u) ? 0xffffu : 0u) | ((k & 8u) ? 0xffff0000u : 0u));
+                    else s_keep[i] = (uint8_t)k;
+                };
+                if (lut_al) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (4 * t + j < BFPQ_NM4_LUT_ENTRIES) put(4 * t + j, (k4 >> (8 * j)) & 0xffu);
+                } else
+                    for (int i = t; i < BFPQ_NM4_LUT_ENTRIES; i += kThreads) put(i, a.nm_lut[i]);
+            }
+        }
+        __syncthreads();
+        // (one more memory operation behind the first load, result unused: see the flat sweep below -- with [load, dummy] on
+        // the entry edge and [load, store] on the back edge the loop-top wait can leave the previous store in flight)
+#if BFPQ_BUF_DUMMY
+        asm volatile("" ::: "memory");
+        const uint32_t dummy = *reinterpret_cast<const uint32_t*>(a.in);
+        asm volatile("" ::: "memory");
+#endif
+        const int64_t pairs = ((a.n_items + stride - 1) / stride + 1) / 2;     // sweeps, two per trip (a sweep past the end is all out of range)
+        for (int64_t p = 0; p < pairs; p++) {
+            const uint4 c1 = bload(sb);
+            body(std::false_type{}, 0, c0);
+            bstore(buf_res, 0);
+            c0 = bload(2 * sb);
+            body(std::false_type{}, 0, c1);
+            bstore(buf_res, sb);
+            voff += 2 * sb;
+        }
+#if BFPQ_BUF_DUMMY
+        asm volatile("" : : "v"(dummy));
+#endif
         return;
     }
     // Sweep: item = sweep * stride + global thread id.  Loads run two sweeps ahead of the item being
@@ -1073,8 +1155,25 @@ __global__ void __launch_bounds__(kThreads) k_quant_rows_vec(const void* in, voi
 }
 
 template <int DT, int NM, bool SFIRST, bool STOCH, bool DEQ_ONLY>
-int launch_fused_o(const FusedArgs& a, hipStream_t s)
+int launch_fused_o(const FusedArgs& a0, hipStream_t s)
 {
+    FusedArgs a = a0;
+    if constexpr (DEQ_ONLY && !STOCH && NM != -1) {
+        // these instantiations address the tensor through 32-bit buffer offsets (items + three sweeps of look-ahead must stay
+        // below 4 GB): a larger tensor goes in pieces of 2^27 items (2 GB), whole blocks and whole chunks of 256 items each
+        const int64_t piece = (int64_t)1 << 27;
+        if (a0.n_items > piece + (piece >> 1)) {
+            for (int64_t i0 = 0; i0 < a0.n_items; i0 += piece) {
+                FusedArgs b = a0;
+                b.in = reinterpret_cast<const char*>(a0.in) + i0 * 16;
+                b.out_deq = reinterpret_cast<char*>(a0.out_deq) + i0 * 16;
+                b.n_items = a0.n_items - i0 < piece ? a0.n_items - i0 : piece;
+                const int rc = launch_fused_o<DT, NM, SFIRST, STOCH, DEQ_ONLY>(b, s);
+                if (rc) return rc;
+            }
+            return 0;
+        }
+    }
     const dim3 grid(grid_for(a.n_items)), block(kThreads);
     if constexpr (!STOCH && NM != 2) {           // the shapes that matter get a compile-time lane group
         switch (a.lpb) {
@@ -1116,6 +1215,19 @@ int launch_fused_threshold(const FusedArgs& a, hipStream_t s)
 template <int DT, bool SFIRST, bool STOCH>
 int launch_fused_nm8(const FusedArgs& a, hipStream_t s)
 {
+    const bool deq_only0 = a.out_deq && !a.out_codes && !a.out_exp;
+    const int64_t piece = (int64_t)1 << 27;                   // (see launch_fused_o: 32-bit buffer offsets in the drop-in instantiations)
+    if (!STOCH && deq_only0 && a.n_items > piece + (piece >> 1)) {
+        for (int64_t i0 = 0; i0 < a.n_items; i0 += piece) {
+            FusedArgs b = a;
+            b.in = reinterpret_cast<const char*>(a.in) + i0 * 16;
+            b.out_deq = reinterpret_cast<char*>(a.out_deq) + i0 * 16;
+            b.n_items = a.n_items - i0 < piece ? a.n_items - i0 : piece;
+            const int rc = launch_fused_nm8<DT, SFIRST, STOCH>(b, s);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     const dim3 grid(grid_for(a.n_items)), block(kThreads);
     const bool deq_only = a.out_deq && !a.out_codes && !a.out_exp;
     if constexpr (STOCH) hipLaunchKernelGGL((k_fused_flat<DT, 8, SFIRST, true, -1, false>), grid, block, 0, s, a);

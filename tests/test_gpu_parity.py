@@ -946,3 +946,24 @@ def test_prepared_list_reruns_in_place():
     b = prep.run()
     for w, y in zip(ws, b):
         assert torch.equal(y, bfp_ops.float_to_bfp_blocked(w, **c, identifier='w'))
+
+
+def test_tensor_above_4gb_is_cut_into_pieces():
+    """A 5 GiB bf16 tensor (the drop-in kernels address through 32-bit buffer offsets, so the launcher cuts it into
+    2 GiB pieces): rows are independent, so every row slab must equal the same rows quantized on their own -- dense, 2:4 and
+    4:8 -- and a sample of rows is held to the oracle."""
+    rows, cols = 40960, 65536                                           # 2.68 G elements = 5 GiB
+    g = torch.Generator(device=DEV).manual_seed(77)
+    x = torch.empty(rows, cols, dtype=torch.bfloat16, device=DEV)
+    for r0 in range(0, rows, 4096):
+        x[r0:r0 + 4096] = (torch.randn(4096, cols, generator=g, device=DEV) * 0.02).to(torch.bfloat16)
+    for c in (cfg(w_sparsity=True), cfg(), cfg(w_sparsity=True, N=4, M=8)):
+        y = bfp_ops.float_to_bfp_blocked(x, **c, identifier='w')
+        for r0 in (0, 12288, 16384 - 64, 32768 - 8, rows - 4096):          # slabs inside pieces and across the piece boundaries
+            part = bfp_ops.float_to_bfp_blocked(x[r0:r0 + 4096].contiguous(), **c, identifier='w')
+            assert torch.equal(y[r0:r0 + 4096], part), (c['N'], c['M'], r0)
+        sample = torch.cat([x[16383:16385], x[-2:]]).cpu()
+        want = O.float_to_bfp_blocked(sample, **c, identifier='w')
+        got = torch.cat([y[16383:16385], y[-2:]]).cpu()
+        assert_bits_equal(bits(got), bits(want), torch.bfloat16, f"rows around a piece boundary {c['N']}:{c['M']}")
+        del y
