@@ -33,7 +33,7 @@ def main():
                                     ("down_proj decode", 16, 11008, 4096), ("gate_proj decode", 16, 4096, 11008), ("down_proj decode 1 token", 1, 11008, 4096),
                                     ("down_proj decode 64 tokens", 64, 11008, 4096)):
         x = (torch.randn(tokens, fin, device=dev) * 1.0).to(torch.bfloat16)
-        lin = bfp_ops.BFPLinear(fin, fout, False, **dict(cfg)).to(dev).to(torch.bfloat16)
+        lin = bfp_ops.BFPLinear(fin, fout, False, **dict(cfg)).to(dev).to(torch.bfloat16).eval()     # (the weight cache is inference-only)
         with torch.no_grad():
             plain = timeit(lambda: torch.nn.functional.linear(x, lin.weight))
             ref = timeit(lambda: lin(x))

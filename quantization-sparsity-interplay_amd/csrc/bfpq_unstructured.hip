@@ -197,9 +197,19 @@ __global__ void __launch_bounds__(kResThreads) k_select_resolve(const void* in, 
     } else {
         const int nbins = 1 << nbits;                       // 2048 or 512: eight or two contiguous bins per thread
         const int per = nbins / kResThreads;
-        uint32_t v[8], mine = 0;
+        uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mine = 0;
+        for (int r = 0; r < n_hists; r++) {                 // a thread's bins are contiguous: 16-byte / 8-byte loads per copy
+            const uint32_t* h = hist_all + (size_t)r * BFPQ_SELECT_HIST_ENTRIES + t * per;
+            if (per == 8) {
+                const uint4 a4 = *reinterpret_cast<const uint4*>(h), b4 = *reinterpret_cast<const uint4*>(h + 4);
+                v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w; v[4] += b4.x; v[5] += b4.y; v[6] += b4.z; v[7] += b4.w;
+            } else {
+                const uint2 a2 = *reinterpret_cast<const uint2*>(h);
+                v[0] += a2.x; v[1] += a2.y;
+            }
+        }
 #pragma unroll
-        for (int j = 0; j < 8; j++) { v[j] = j < per ? sum_h(t * per + j) : 0u; mine += v[j]; }
+        for (int j = 0; j < 8; j++) mine += v[j];
         uint32_t excl = block_excl_scan(mine, s_part, &total);
         if (mine && excl < k_rem && k_rem <= excl + mine) {
             int j = 0;
