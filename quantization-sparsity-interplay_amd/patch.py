@@ -41,22 +41,54 @@ class PackedBFPLinear(torch.nn.Module):
     """Inference-only Linear whose weight lives in packed HBFP form (4-bit codes + one int8 exponent per block of 64:
     0.516 B per weight instead of 2) -- what a BFPLinear with w_sparsity / HBFP4 computes in its forward, with the weight
     quantized ONCE.  Up to 64 tokens the product comes straight from the codes (integer block dot products on the int8
-    matrix cores, PackedBFP.linear_decode); more tokens decode the weight and use the library GEMM."""
+    matrix cores, PackedBFP.linear_decode); more tokens decode the weight and use the library GEMM.
+    The codes and exponents are registered buffers (`codes`, `exps`): they follow .to() / .cuda(), appear in state_dict()
+    and load back with load_state_dict(); shape / dtype / mantissa width travel as extra state."""
 
     def __init__(self, packed, bias=None, x_mant_bits=7, epsilon=1e-8):
         super().__init__()
-        self.packed = packed
         self.out_features, self.in_features = packed.shape
         self.x_mant_bits, self.epsilon = int(x_mant_bits), float(epsilon)
+        self.register_buffer("codes", packed.codes)
+        self.register_buffer("exps", packed.exps)
+        self._meta = dict(shape=list(packed.shape), dtype=str(packed.dtype).replace("torch.", ""), mant_bits=packed.mant_bits,
+                          block_size=packed.block_size, code_bits=packed.code_bits)
+        self._packed = packed
         self.bias = None if bias is None else torch.nn.Parameter(bias.detach(), requires_grad=False)
+
+    @property
+    def packed(self):
+        """the PackedBFP view of the buffers (rebuilt when .to() / load_state_dict() replaced them; the MFMA-tiled copy of the
+        decode kernel is then re-made lazily on the new device)"""
+        p = self._packed
+        if p is None or p.codes is not self.codes or p.exps is not self.exps:
+            m = self._meta
+            p = self._packed = bfp_ops.PackedBFP(self.codes, self.exps, tuple(m['shape']), getattr(torch, m['dtype']), m['mant_bits'],
+                                                 m['block_size'], m['code_bits'])
+        return p
+
+    def get_extra_state(self):
+        return dict(self._meta, x_mant_bits=self.x_mant_bits, epsilon=self.epsilon)
+
+    def set_extra_state(self, state):
+        self._meta = {k: state[k] for k in ('shape', 'dtype', 'mant_bits', 'block_size', 'code_bits')}
+        self.x_mant_bits, self.epsilon = int(state['x_mant_bits']), float(state['epsilon'])
+        self._packed = None
 
     @classmethod
     def from_linear(cls, lin, bfp_args):
-        """weight -> float_to_bfp_packed with the module's config (format 'bfp', block 64, mant_bits <= 3; N:M from
-        the w_sparsity keys, order from `first`); activations use mant_bits of the same config"""
+        """weight -> float_to_bfp_packed with the module's config (format 'bfp', block 64, mant_bits <= 3, round-half-even;
+        N:M from the w_sparsity keys, order from `first`); activations use mant_bits of the same config.  Configurations this
+        module cannot reproduce (unstructured weight pruning, pruned activations, stochastic rounding) are refused."""
         a = bfp_ops.unpack_bfp_args(dict(bfp_args))
         assert a['num_format'] == 'bfp' and a['sparsity_num_format'] == 'bfp' and a['block_size'] == 64 and 1 <= a['mant_bits'] <= 3, \
             "PackedBFPLinear holds 4-bit codes: an HBFP config with block_size 64 and mant_bits <= 3 (HBFP4)"
+        if a['w_sparsity'] and a['sparsity_mode'] != 'structured':
+            raise ValueError("PackedBFPLinear: unstructured weight pruning is not packed here (use structured N:M, or prune the weight first)")
+        if a['in_sparsity']:
+            raise ValueError("PackedBFPLinear quantizes activations densely: in_sparsity is not reproduced")
+        if a['rounding_mode'] != 'determ':
+            raise ValueError("PackedBFPLinear packs with round-half-even: rounding_mode must be 'determ'")
         sp = a['w_sparsity'] and a['sparsity_mode'] == 'structured'
         pw = bfp_ops.PackedBFP.quantize(lin.weight.detach(), a['mant_bits'], 64, a['epsilon'], a['N'] if sp else 0, a['M'] if sp else 0, a['first'])
         return cls(pw, lin.bias, a['mant_bits'], a['epsilon'])

@@ -92,6 +92,21 @@ def test_packed_inference_model_matches_fake_quantised_model():
             a, b = fake(tokens).logits, packed(tokens).logits
         err = float((a - b).abs().max() / a.abs().max())
         assert err < 2e-3, (shape, err)                                     # same quantised operands; accumulation order differs
+    # the packed weights are buffers: they are in the state dict, survive a round trip through it, and follow .to()
+    sd = packed.state_dict()
+    key = "model.layers.1.mlp.down_proj.codes"
+    assert key in sd and sd[key].dtype == torch.uint8 and "model.layers.1.mlp.down_proj.exps" in sd
+    clone = copy.deepcopy(base).to("cuda:0")
+    pack_linear_layers(clone, args)
+    for m in clone.modules():
+        if isinstance(m, PackedBFPLinear):
+            m.codes.zero_()                                                    # wipe, then restore from the state dict
+    clone.load_state_dict(sd)
+    tokens = torch.randint(0, 1000, (1, 12), generator=torch.Generator().manual_seed(5)).to("cuda:0")
+    with torch.no_grad():
+        assert torch.equal(clone(tokens).logits, packed(tokens).logits)
+    with pytest.raises(ValueError):
+        PackedBFPLinear.from_linear(torch.nn.Linear(256, 64).to("cuda:0"), dict(args, sparsity_mode='unstructured'))
 
 
 @pytest.mark.gpu
