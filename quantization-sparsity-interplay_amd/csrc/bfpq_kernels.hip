@@ -6,14 +6,13 @@
 //   k_fused_flat   the hot kernel: [N:M mask] + shared exponent + mantissa rounding in ONE pass.
 //                  16 B per lane per access, a block of `block_size` elements lives in `lpb`
 //                  adjacent lanes of one wavefront (block 64 bf16 = 8 lanes), block max by
-//                  cross-lane xor-shuffles, N:M keep-mask from a 729-entry LDS table, no atomics,
-//                  no LDS staging of data, no second read.  HBM-bound: 2 x sizeof(dtype) B/elem.
+//                  DPP, N:M keep-mask from a 729-entry LDS table, no atomics, no LDS staging of data,
+//                  no second read.  HBM-bound: 2 x sizeof(dtype) B/elem.  NM == -1: global magnitude
+//                  threshold (the apply launch of the unstructured path, bfpq_unstructured.hip).
+//   k_fused_batched  the same item pipeline over a list of tensors (descriptors in the kernel arguments)
 //   k_nm_rows      general N:M (any M <= 64, ragged rows): one thread per group, the group's
 //                  (key,index) pairs in an LDS column, libstdc++ introselect replayed (nm_select.h)
-//   k_quant_rows   general HBFP quantizer (any block size, ragged rows): a power-of-two lane group
-//                  per block, two sweeps (max, then quantize)
-//   k_select_*     radix select of the k-th smallest magnitude (LDS histogram, then a 1-block scan)
-//   k_tie_count / k_tie_scan / k_threshold_apply   ordered tie ranks + zeroing for unstructured pruning
+//   k_quant_rows_tiled / _vec / k_quant_rows   HBFP quantizers for ragged rows and odd block sizes
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
