@@ -125,6 +125,39 @@ struct FusedArgs {
     SelWs* selws;             // NM == -1 (global magnitude threshold): the select workspace (threshold + tie bookkeeping)
 };
 
+// A list of tensors in one launch (bfpq_fake_quantize_batched): up to kMaxBatch descriptors travel in the kernel arguments
+// (no device memory, graph-capturable).  The tensors share dtype / block / mantissa width; each is a flat array of lane
+// items cut into chunks of 256 (the last chunk of a tensor is ragged), the chunks of all tensors form one index space
+// that the workgroups stride over.  flags bit 0: apply the N:M mask to this tensor (a Linear's weight) or not (its activation).
+constexpr int kMaxBatch = 64;
+struct BatchDesc { const void* in; void* out; int64_t n_items; uint32_t chunk0; uint32_t flags; };
+struct BatchArgs { int n; uint32_t total_chunks; BatchDesc d[kMaxBatch]; };
+
+
+// the fused kernels are compiled once per dtype (bfpq_fused_dt.hip); these are their launchers, dtype in the name
+#define BFPQ_HIDDEN __attribute__((visibility("hidden")))
+BFPQ_HIDDEN int fused_launch_0(const FusedArgs& a, int M, bool sfirst, hipStream_t s);
+BFPQ_HIDDEN int fused_launch_1(const FusedArgs& a, int M, bool sfirst, hipStream_t s);
+BFPQ_HIDDEN int fused_launch_2(const FusedArgs& a, int M, bool sfirst, hipStream_t s);
+BFPQ_HIDDEN int fused_threshold_0(const FusedArgs& a, hipStream_t s);
+BFPQ_HIDDEN int fused_threshold_1(const FusedArgs& a, hipStream_t s);
+BFPQ_HIDDEN int fused_threshold_2(const FusedArgs& a, hipStream_t s);
+BFPQ_HIDDEN int fused_batched_0(const FusedArgs& a, const BatchArgs& b, int M, bool sfirst, hipStream_t s);
+BFPQ_HIDDEN int fused_batched_1(const FusedArgs& a, const BatchArgs& b, int M, bool sfirst, hipStream_t s);
+BFPQ_HIDDEN int fused_batched_2(const FusedArgs& a, const BatchArgs& b, int M, bool sfirst, hipStream_t s);
+inline int fused_launch(int dtype, const FusedArgs& a, int M, bool sfirst, hipStream_t s)
+{
+    return dtype == BFPQ_F32 ? fused_launch_0(a, M, sfirst, s) : (dtype == BFPQ_F16 ? fused_launch_1(a, M, sfirst, s) : fused_launch_2(a, M, sfirst, s));
+}
+inline int fused_threshold(int dtype, const FusedArgs& a, hipStream_t s)
+{
+    return dtype == BFPQ_F32 ? fused_threshold_0(a, s) : (dtype == BFPQ_F16 ? fused_threshold_1(a, s) : fused_threshold_2(a, s));
+}
+inline int fused_batched(int dtype, const FusedArgs& a, const BatchArgs& b, int M, bool sfirst, hipStream_t s)
+{
+    return dtype == BFPQ_F32 ? fused_batched_0(a, b, M, sfirst, s) : (dtype == BFPQ_F16 ? fused_batched_1(a, b, M, sfirst, s) : fused_batched_2(a, b, M, sfirst, s));
+}
+
 // wave-level inclusive scan (lane order) by DPP: row_shr 1/2/4/8 inside the rows of 16 lanes, then row_bcast15 /
 // row_bcast31 carry the row totals forward (six VALU adds; the ds_bpermute form is six LDS round trips)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)

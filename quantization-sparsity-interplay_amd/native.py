@@ -38,7 +38,7 @@ def lib_path():
 
 def build_library(force=False):
     """Compile csrc/ for gfx950 with hipcc (cross-compiles without a GPU)."""
-    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-s"]
+    args = ["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j8"]
     if force:
         args.append("-B")
     subprocess.check_call(args)
