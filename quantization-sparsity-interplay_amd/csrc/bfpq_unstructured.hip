@@ -128,11 +128,16 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
     // all workgroups adding into one copy every hot address takes 256 serialised adds (~3 us behind the streaming loop).
     // The LDS reads of a thread are issued together.
     if (nbits == 15) {
-        uint32_t c[32];
-#pragma unroll
-        for (int j = 0; j < 32; j++) c[j] = s_hist[t + j * kSelThreads];
-#pragma unroll
-        for (int j = 0; j < 32; j++) if (c[j]) atomicAdd(&hist[t + j * kSelThreads], c[j]);
+        // one coarse bin (128 fine bins, two 256-byte atomic wave-instructions) per wave and trip; the empty ones -- all but
+        // 15-20 of the 256 for a weight tensor -- are skipped on their coarse sum
+        const int lane = t & 63;
+        for (int cb = t >> 6; cb < kCoarseBins; cb += kSelThreads / 64) {
+            if (s_coarse[cb] == 0) continue;                   // (wave-uniform)
+            const int i = cb * 128 + lane;
+            const uint32_t c0 = s_hist[i], c1 = s_hist[i + 64];
+            if (c0) atomicAdd(&hist[i], c0);
+            if (c1) atomicAdd(&hist[i + 64], c1);
+        }
     } else {
         for (int i = t; i < nbins; i += kSelThreads) {
             const uint32_t c = s_hist[i];
