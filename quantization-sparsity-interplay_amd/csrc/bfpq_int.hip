@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(kT) k_int_cols_minmax(const void* in, int64_t 
     }
     if (nan) { mn = u2f(0xffc00000u); mx = u2f(0x7fc00000u); }     // keys: -NaN smallest, +NaN largest
     atomicMin(&ws[col], f_key(mn));
-    atomicMax(&ws[C + col], f_key(mx));
+    atomicMin(&ws[C + col], ~f_key(mx));
 }
 
 template <int DT>
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(kT) k_int_cols_quant(const void* in, float* ou
 {
     const int64_t col = (int64_t)blockIdx.x * kT + threadIdx.x;
     if (col >= C) return;
-    const float scale = int_scale(key_f(ws[col]), key_f(ws[C + col]), maxq);
+    const float scale = int_scale(key_f(ws[col]), key_f(~ws[C + col]), maxq);
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
     const int64_t r1 = r0 + rows_per_chunk < outer ? r0 + rows_per_chunk : outer;
     for (int64_t r = r0; r < r1; r++) out[r * C + col] = int_q(ldf<DT>(in, r * C + col), scale, zero, maxq);
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(kT) k_int_cols_minmax_vec(const void* in, int6
         const int64_t col = col0 + j * kT + threadIdx.x;
         if (col < C) {
             atomicMin(&ws[col], s_mn[j * kT + threadIdx.x]);
-            atomicMax(&ws[C + col], s_mx[j * kT + threadIdx.x]);
+            atomicMin(&ws[C + col], ~s_mx[j * kT + threadIdx.x]);
         }
     }
 }
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(kT) k_int_cols_quant_vec(const void* in, float
     if (cg >= ipr) return;
     float scale[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; j++) scale[j] = int_scale(key_f(ws[cg * VEC + j]), key_f(ws[C + cg * VEC + j]), maxq);
+    for (int j = 0; j < VEC; j++) scale[j] = int_scale(key_f(ws[cg * VEC + j]), key_f(~ws[C + cg * VEC + j]), maxq);
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
     const int64_t r1 = r0 + rows_per_chunk < outer ? r0 + rows_per_chunk : outer;
 #pragma unroll 4
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(kT) k_int_seg_minmax(const void* in, int64_t o
         }
         wave_minmax(mn, mx, nan);
         if (nan) { mn = u2f(0xffc00000u); mx = u2f(0x7fc00000u); }
-        if (lane == 0) { atomicMin(&ws[seg % C], f_key(mn)); atomicMax(&ws[C + seg % C], f_key(mx)); }
+        if (lane == 0) { atomicMin(&ws[seg % C], f_key(mn)); atomicMin(&ws[C + seg % C], ~f_key(mx)); }
     }
 }
 
@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(kT) k_int_seg_quant(const void* in, float* out
     const int64_t nseg = outer * C;
     for (int64_t seg = ((int64_t)blockIdx.x * kT + threadIdx.x) >> 6; seg < nseg; seg += (int64_t)gridDim.x * (kT / 64)) {
         const int64_t c = seg % C;
-        const float scale = int_scale(key_f(ws[c]), key_f(ws[C + c]), maxq);
+        const float scale = int_scale(key_f(ws[c]), key_f(~ws[C + c]), maxq);
         for (int64_t i = lane; i < inner; i += 64) out[seg * inner + i] = int_q(ldf<DT>(in, seg * inner + i), scale, zero, maxq);
     }
 }
@@ -437,9 +437,8 @@ int run_int(const void* in, float* out, int64_t outer, int64_t C, int64_t inner,
         return (int)hipGetLastError();
     }
     if (!ws) return BFPQ_E_ARG;
-    hipError_t e = hipMemsetAsync(ws, 0xff, sizeof(uint32_t) * C, s);            // min keys start at the top
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(ws + C, 0x00, sizeof(uint32_t) * C, s);                   // max keys start at the bottom
+    // min keys start at the top; the max keys are kept INVERTED (atomicMin on ~key) so that one fill serves both arrays
+    hipError_t e = hipMemsetAsync(ws, 0xff, sizeof(uint32_t) * 2 * C, s);
     if (e != hipSuccess) return (int)e;
     if (inner == 1 && C % Traits<DT>::VEC == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0) {
         const int64_t ipr = C / Traits<DT>::VEC;

@@ -967,3 +967,21 @@ def test_tensor_above_4gb_is_cut_into_pieces():
         got = torch.cat([y[16383:16385], y[-2:]]).cpu()
         assert_bits_equal(bits(got), bits(want), torch.bfloat16, f"rows around a piece boundary {c['N']}:{c['M']}")
         del y
+
+
+def test_unstructured_on_two_streams_concurrently():
+    """the select workspace is per (device, stream): two unstructured calls in flight on two streams must not see each
+    other's threshold state"""
+    xs = [synth(2048, 4096, torch.bfloat16, 0.02, seed=s).to(DEV) for s in (21, 22)]
+    cs = [cfg(w_sparsity=True, sparsity_mode='unstructured', sparsity_frac=f, first='s') for f in (0.3, 0.7)]
+    want = [bfp_ops.float_to_bfp_blocked(x, **c, identifier='w').clone() for x, c in zip(xs, cs)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = [None, None]
+    for rep in range(5):
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                got[i] = bfp_ops.float_to_bfp_blocked(xs[i], **cs[i], identifier='w')
+        torch.cuda.synchronize()
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), rep
+    assert bfp_ops._workspace.__doc__ and len({id(ws) for ws in bfp_ops._select_ws.values()}) >= 2
