@@ -17,7 +17,7 @@ namespace bfpq_dev {
 //   wider than the dtype) makes the whole wavefront replay that item through the step-by-step
 //   emulation (quant_elem); the branch is wave-uniform and never taken on ordinary weights.
 // ---------------------------------------------------------------------------------------------
-template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY, bool BATCHED>
+template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY, bool BATCHED, bool F32IMG = false>
 __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unused]] const BatchArgs* b)
 {
     using T = Traits<DT>;
@@ -312,7 +312,16 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
                 } else {
                     typedef float float2v __attribute__((ext_vector_type(2)));
                     float y[VEC];
-                    [[maybe_unused]] const uint32_t rkey = STOCH ? rng_item_key(a.seed, (uint64_t)item * VEC) : 0u;
+                    // stochastic rounding: the per-item key goes once through the two-multiply mixer, then one xorshift32 step
+                    // yields the two 16-bit dithers of a pair of elements (32-bit integer multiplies are quarter rate on this
+                    // part: the per-element mixer made 'stoc' VALU-bound); a dither is built as the float 1.f + u 2^-16 and the
+                    // -1.5 that centres it rides in the scaling FMA
+                    [[maybe_unused]] uint32_t rstate = 0u;
+                    if constexpr (STOCH) {
+                        uint32_t x = rng_item_key(a.seed, (uint64_t)item * VEC);
+                        x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+                        rstate = x | 1u;
+                    }
     #pragma unroll
                     for (int j = 0; j < VEC; j += 2) {                     // two elements per v_pk_mul_f32
                         float2v x;
@@ -320,11 +329,12 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
                             const uint32_t d = j < 2 ? d0 : (j < 4 ? d1 : (j < 6 ? d2 : d3));
                             x = (float2v){u2f(d << 16), u2f(d & 0xffff0000u)};
                         } else x = (float2v){raw_to_f32<DT>(raw[j]), raw_to_f32<DT>(raw[j + 1])};
-                        float2v t = x * (float2v){fs.inv, fs.inv};
+                        float2v t;
                         if constexpr (STOCH) {
-                            t.x += uniform24k(rkey, (uint32_t)j) - 0.5f;
-                            t.y += uniform24k(rkey, (uint32_t)j + 1u) - 0.5f;
-                        }
+                            rstate ^= rstate << 13; rstate ^= rstate >> 17; rstate ^= rstate << 5;
+                            const float2v u = {u2f(0x3f800000u | ((rstate & 0xffffu) << 7)), u2f(0x3f800000u | ((rstate >> 16) << 7))};   // [1, 2)
+                            t = __builtin_elementwise_fma(x, (float2v){fs.inv, fs.inv}, (float2v){-1.5f, -1.5f}) + u;   // x / interval + uniform[-0.5, 0.5)
+                        } else t = x * (float2v){fs.inv, fs.inv};
                         float2v q = {__builtin_amdgcn_fmed3f(rintf(t.x), -fs.qmax, fs.qmax), __builtin_amdgcn_fmed3f(rintf(t.y), -fs.qmax, fs.qmax)};
                         code[j] = q.x; code[j + 1] = q.y;
                         const float2v yy = q * (float2v){fs.interval, fs.interval};
@@ -360,6 +370,21 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
             }
         }
         if constexpr (USE_BUF) { buf_res = make_uint4(o0, o1, o2, o3); return; }   // (the sweep stores it)
+        if constexpr (F32IMG) {
+            // the fp32 image of the result and nothing else (what 'stoc' rounding of a half tensor returns): two
+            // unconditional-in-form stores per item, like the drop-in mode's one
+            static_assert(VEC == 8, "fp32 image: 16-bit inputs");
+            const uint32_t od[4] = {o0, o1, o2, o3};
+            uint32_t f[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; j++) f[j] = f2u(raw_to_f32<DT>((od[j >> 1] >> (16 * (j & 1))) & 0xffffu));
+            if (valid) {
+                uint4* dst = reinterpret_cast<uint4*>(a.out_codes) + item * 2;
+                dst[0] = make_uint4(f[0], f[1], f[2], f[3]);          // (plain stores: the two halves of a 32-byte piece meet in L2;
+                dst[1] = make_uint4(f[4], f[5], f[6], f[7]);          //  non-temporal ones measured 66.5 vs 58 us)
+            }
+            return;
+        }
         if constexpr (DEQ_ONLY) {                                           // hot mode: exactly one store per item
             if (valid) stream_store(reinterpret_cast<uint4*>(out_deq) + item, make_uint4(o0, o1, o2, o3));
             return;
@@ -619,10 +644,10 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
     asm volatile("" : : "v"(dummy));                                       // the dummy's only "use": after all the work
 }
 
-template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY>
+template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY, bool F32IMG = false>
 __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
 {
-    fused_flat_body<DT, NM, SFIRST, STOCH, LPBT, DEQ_ONLY, false>(a, nullptr);
+    fused_flat_body<DT, NM, SFIRST, STOCH, LPBT, DEQ_ONLY, false, F32IMG>(a, nullptr);
 }
 
 // the same item pipeline over a list of tensors (drop-in mode, round-half-even, dense or N:4)
@@ -682,6 +707,13 @@ int launch_fused_l(const FusedArgs& a, hipStream_t s)
 {
     const bool deq_only = a.out_deq && !a.out_codes && !a.out_exp;
     if (deq_only) return launch_fused_o<DT, NM, SFIRST, STOCH, true>(a, s);
+    if constexpr (STOCH && Traits<DT>::VEC == 8) {
+        if (!a.out_deq && a.out_codes && a.code_bits == 32 && !a.out_exp) {      // fp32 image only: its own store-lean instantiation
+            const dim3 grid(grid_for(a.n_items)), block(kThreads);
+            hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, true, -1, false, true>), grid, block, 0, s, a);
+            return (int)hipGetLastError();
+        }
+    }
     return launch_fused_o<DT, NM, SFIRST, STOCH, false>(a, s);
 }
 
