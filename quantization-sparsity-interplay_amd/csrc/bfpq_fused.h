@@ -17,7 +17,7 @@ namespace bfpq_dev {
 //   wider than the dtype) makes the whole wavefront replay that item through the step-by-step
 //   emulation (quant_elem); the branch is wave-uniform and never taken on ordinary weights.
 // ---------------------------------------------------------------------------------------------
-template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY, bool BATCHED, bool F32IMG = false>
+template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY, bool BATCHED, bool F32IMG = false, bool PACK4 = false>
 __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unused]] const BatchArgs* b)
 {
     using T = Traits<DT>;
@@ -242,6 +242,9 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
         for (int j = 0; j < VEC; j++) code[j] = 0.f;
         int e_blk = 0;
         bool nan_blk = false;
+        [[maybe_unused]] uint32_t pack_w = 0;                     // PACK4: the item's eight 4-bit codes, the block's exponent byte
+        [[maybe_unused]] int pack_e = 0;
+        [[maybe_unused]] bool pack_hot = false;
         if (do_quant) {
             // block max of |v| as integer max of magnitude bits
             uint32_t mx;
@@ -257,12 +260,44 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
             mx = group_max<LPBT>(mx, a.lpb);
             bool hot = false;
             [[maybe_unused]] Hot16 h16;
-            if constexpr (VEC == 8 && !STOCH && DEQ_ONLY) {
+            if constexpr (VEC == 8 && !STOCH && (DEQ_ONLY || PACK4)) {
                 h16 = hot16_scale<DT>(mx, a, s_win);
                 hot = !__any(!h16.ok);
             }
+            pack_hot = hot;
             if (__builtin_expect(hot, 1)) {
-                if constexpr (VEC == 8 && !STOCH && DEQ_ONLY) {
+                if constexpr (VEC == 8 && !STOCH && PACK4) {
+                    // Packed output from the lean arithmetic: min(|x|, max_v) + C has the integer mantissa in the LOW bits of
+                    // its float image (ulp(C) = interval and the low 16 bits of C's image are zero), so the magnitude codes of
+                    // two elements are one v_perm of the two sums; sign -> two's complement on packed halves; eight nibbles
+                    // -> one dword.  The eight block exponents of the wave leave as ONE 8-byte store.
+                    static_assert(LPBT == 8, "packed 4-bit instantiation: block = 8 lane items");
+                    const uint32_t absm = T::ABS | (T::ABS << 16);
+                    uint32_t dd[4] = {d0, d1, d2, d3}, q[4];
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        const uint32_t am = pk_min_u16(dd[x] & absm, h16.maxv2);
+                        typedef float float2v __attribute__((ext_vector_type(2)));
+                        const float2v C2 = {h16.C, h16.C};
+                        float2v v;
+                        if constexpr (DT == BFPQ_BF16) v = (float2v){u2f(am << 16), u2f(am & 0xffff0000u)} + C2;
+                        else v = (float2v){fma_mix_f16<false>(am, h16.C), fma_mix_f16<true>(am, h16.C)};
+                        q[x] = __builtin_amdgcn_perm(f2u(v.y), f2u(v.x), 0x05040100u);             // (q_hi << 16) | q_lo
+                    }
+                    if constexpr (NM != 0 && !SFIRST) nm_mask(q[0], q[1], q[2], q[3]);   // Q before S: inside a block codes order like values
+                    uint32_t c[4];
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        const uint32_t m = pk_ashr_i16_s(dd[x], 0x000f000fu);                     // 0xffff where the element is negative
+                        c[x] = pk_sub_i16(q[x] ^ m, m);                                            // two's complement per half
+                    }
+                    // eight low nibbles -> one dword: low bytes of the halves side by side, then nibbles of adjacent bytes together
+                    uint32_t p0 = __builtin_amdgcn_perm(c[1], c[0], 0x06040200u) & 0x0f0f0f0fu;   // [c0.lo, c0.hi, c1.lo, c1.hi]
+                    uint32_t p1 = __builtin_amdgcn_perm(c[3], c[2], 0x06040200u) & 0x0f0f0f0fu;
+                    p0 |= p0 >> 4; p1 |= p1 >> 4;                                                  // bytes 0 and 2 now hold two nibbles each
+                    pack_w = __builtin_amdgcn_perm(p1, p0, 0x06040200u);
+                    pack_e = h16.e;
+                } else if constexpr (VEC == 8 && !STOCH && DEQ_ONLY) {
                     const uint32_t absm = T::ABS | (T::ABS << 16);
                     const uint32_t dd[4] = {d0, d1, d2, d3};
                     uint32_t oo[4];
@@ -355,7 +390,7 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
                 }
             }
         }
-        if constexpr (NM != 0 && !SFIRST) {                                   // Q before S (bfp_ops.py:146-149)
+        if constexpr (NM != 0 && !SFIRST) if (!(PACK4 && pack_hot)) {                // Q before S (bfp_ops.py:146-149)
             if constexpr (BATCHED) { if (nm_on) nm_mask(o0, o1, o2, o3); }
             else nm_mask(o0, o1, o2, o3);
             if (a.out_codes) {                                                // a pruned element has code 0
@@ -368,6 +403,32 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
                     for (int j = 0; j < VEC; j++) code[j] = ((od[j >> 1] >> (16 * (j & 1))) & T::ABS) ? code[j] : 0.f;
                 }
             }
+        }
+        if constexpr (PACK4) {
+            // the packed item from whichever tier ran; then stores that are unconditional in form (a store inside a branch makes
+            // hipcc drain the memory queue at the loop top): every lane its code dword, and the wave's eight exponent bytes as
+            // ONE 8-byte value that all lanes write to the same address
+            if (!pack_hot) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int j = 0; j < VEC; j++) w |= ((uint32_t)(int)code[j] & 0xfu) << (4 * j);
+                pack_w = w;
+                pack_e = nan_blk ? -128 : (e_blk < -127 ? -127 : (e_blk > 127 ? 127 : e_blk));
+            }
+            if constexpr (!GUARD) {
+                reinterpret_cast<uint32_t*>(a.out_codes)[item] = pack_w;
+                const int e8 = pack_e & 0xff;
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(e8, 0) | ((uint32_t)__builtin_amdgcn_readlane(e8, 8) << 8) |
+                                    ((uint32_t)__builtin_amdgcn_readlane(e8, 16) << 16) | ((uint32_t)__builtin_amdgcn_readlane(e8, 24) << 24);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane(e8, 32) | ((uint32_t)__builtin_amdgcn_readlane(e8, 40) << 8) |
+                                    ((uint32_t)__builtin_amdgcn_readlane(e8, 48) << 16) | ((uint32_t)__builtin_amdgcn_readlane(e8, 56) << 24);
+                const int64_t tile0 = uniform64(item - (threadIdx.x & 63));
+                *reinterpret_cast<uint2*>(a.out_exp + (tile0 >> 3)) = make_uint2(lo, hi);
+            } else if (valid) {
+                reinterpret_cast<uint32_t*>(a.out_codes)[item] = pack_w;
+                if ((item & 7) == 0) a.out_exp[item >> 3] = (int8_t)pack_e;
+            }
+            return;
         }
         if constexpr (USE_BUF) { buf_res = make_uint4(o0, o1, o2, o3); return; }   // (the sweep stores it)
         if constexpr (F32IMG) {
@@ -644,10 +705,10 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
     asm volatile("" : : "v"(dummy));                                       // the dummy's only "use": after all the work
 }
 
-template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY, bool F32IMG = false>
+template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY, bool F32IMG = false, bool PACK4 = false>
 __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
 {
-    fused_flat_body<DT, NM, SFIRST, STOCH, LPBT, DEQ_ONLY, false, F32IMG>(a, nullptr);
+    fused_flat_body<DT, NM, SFIRST, STOCH, LPBT, DEQ_ONLY, false, F32IMG, PACK4>(a, nullptr);
 }
 
 // the same item pipeline over a list of tensors (drop-in mode, round-half-even, dense or N:4)
@@ -707,6 +768,14 @@ int launch_fused_l(const FusedArgs& a, hipStream_t s)
 {
     const bool deq_only = a.out_deq && !a.out_codes && !a.out_exp;
     if (deq_only) return launch_fused_o<DT, NM, SFIRST, STOCH, true>(a, s);
+    if constexpr (!STOCH && Traits<DT>::VEC == 8 && NM != 2 && NM != 8) {
+        // packed 4-bit codes + exponents only, block = 8 lane items: the lean packed instantiation
+        if (!a.out_deq && a.out_codes && a.code_bits == 4 && a.out_exp && a.lpb == 8 && (reinterpret_cast<uintptr_t>(a.out_exp) & 7u) == 0) {
+            const dim3 grid(grid_for(a.n_items)), block(kThreads);
+            hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, false, 8, false, false, true>), grid, block, 0, s, a);
+            return (int)hipGetLastError();
+        }
+    }
     if constexpr (STOCH && Traits<DT>::VEC == 8) {
         if (!a.out_deq && a.out_codes && a.code_bits == 32 && !a.out_exp) {      // fp32 image only: its own store-lean instantiation
             const dim3 grid(grid_for(a.n_items)), block(kThreads);

@@ -61,7 +61,7 @@ __device__ __forceinline__ FastScale fast_scale(uint32_t max_key, int mant_bits,
 // The sum is a multiple of ulp(C) = interval, rounded half-to-even by the adder -- the reference's round(x / interval)
 // * interval -- and clamping the magnitude first equals clamping the rounded value (max_v is on the grid).  The clamp is a
 // packed 16-bit integer min on the magnitude bits, the sign comes back with one bit-field insert per two elements.
-struct Hot16 { uint32_t maxv2; float C; bool ok; };
+struct Hot16 { uint32_t maxv2; float C; int e; bool ok; };
 
 template <int DT>
 __device__ __forceinline__ Hot16 hot16_scale(uint32_t max_key, const FusedArgs& a, const uint8_t* s_win)
@@ -73,6 +73,7 @@ __device__ __forceinline__ Hot16 hot16_scale(uint32_t max_key, const FusedArgs& 
     const uint32_t win = s_win[kb + 33u + EOFF];                          // (kb <= 255: inside the 512-byte LDS copy)
     const uint32_t eb = kb + EOFF + (mant > win ? 1u : 0u);               // fp32-biased shared exponent
     h.ok = (kb - (uint32_t)a.kb_lo) <= (uint32_t)a.kb_span;
+    h.e = (int)eb - 127;
     h.C = u2f(((eb - (uint32_t)a.mant_bits) << 23) + 0x0BC00000u);       // 1.5 * 2^(23 + e - m)
     const uint32_t maxv = (eb << T::MBITS) + a.maxv_c;                    // (2^m - 1) * 2^(e - m) in dtype bits
     h.maxv2 = maxv | (maxv << 16);
