@@ -226,6 +226,20 @@ int bfpq_hbfp_linear_decode_tiled(const void* wtiles_dev, const void* wexpt_dev,
                                   void* out_dev, int64_t T, int64_t N, int64_t K,
                                   int out_dtype, int w_mant_bits, int x_mant_bits, void* stream);
 
+/* ---- packed-format consumer for prefill (replaces F.linear on the two fake-quantised operands,
+ * bfp_ops.py:187-190): out[T, N] = x[T, K] W[N, K]^T (+ bias[N]) for any T, both operands HBFP with block 64 and mantissas that
+ * fit e4m3 exactly (mant_bits <= 4), on CDNA4's block-scaled matrix instruction (one v_mfma_scale_f32_32x32x64_f8f6f4 = the
+ * exact integer dot product of one HBFP block times the two power-of-two block scales, fp32 across blocks).
+ * Operand images ("mx8"): e4m3 bytes [rows, K] + E8M0 scale bytes [rows, K/64], made by bfpq_mx8_from_hbfp from the codes
+ * (code_bits 4: two's-complement nibbles, or 8: int8) and int8 exponents that bfpq_quantize_nm writes (exponent -128, the NaN
+ * block marker, becomes the E8M0 NaN).  K % 256 == 0; x8 / w8 16-byte aligned, the scale arrays 4-byte aligned;
+ * bias (nullable) and out of out_dtype. */
+int bfpq_mx8_from_hbfp(const void* codes_dev, const int8_t* exp_dev, void* out8_dev, void* out_scale_dev, int64_t rows, int64_t cols,
+                       int code_bits, int mant_bits, void* stream);
+int bfpq_hbfp_linear_mx8_ok(int64_t T, int64_t N, int64_t K);   /* 1 when the kernel applies */
+int bfpq_hbfp_linear_mx8(const void* x8_dev, const void* xscale_dev, const void* w8_dev, const void* wscale_dev, const void* bias_dev,
+                         void* out_dev, int64_t T, int64_t N, int64_t K, int out_dtype, void* stream);
+
 /* the first BFPQ_SELECT_STATE_BYTES of ws_dev, as read back by a host that wants tau / counts (little-endian) */
 typedef struct bfpq_select_state {
     uint32_t prefix;      /* magnitude bits decided so far (high digits)                         */

@@ -346,9 +346,10 @@ class PackedBFP:
         """F.linear(Q_in(x), W_packed, bias) for any number of tokens, W = self [N, K] (the forward of a BFPLinear whose
         weight is held packed; activations HBFP(x_mant_bits + 1), block 64, round-half-even).
         Up to `decode_tokens` tokens: chunks of 16 through the integer block-dot-product kernel (linear_decode), which
-        never materialises the weight.  More tokens (prefill): the weight is decoded to its dtype once per call
-        (bfpq_dequantize, a streaming pass) and multiplied by the library GEMM -- a compute-bound problem that is not
-        this engine's tier."""
+        never materialises the weight.  More tokens (prefill): when the activation mantissas fit 4 bits (x_mant_bits <= 4)
+        and K % 256 == 0, the block-scaled matrix instruction multiplies the two HBFP operands as they are
+        (native.hbfp_linear_mx8); otherwise the weight is decoded to its dtype once per call (bfpq_dequantize, a
+        streaming pass) and multiplied by the library GEMM."""
         K = self.shape[-1]
         lead = x.shape[:-1]
         x2 = x.reshape(-1, K)
@@ -358,12 +359,22 @@ class PackedBFP:
         if T <= decode_tokens and self.code_bits == 4 and self.block_size == 64 and self.shape[0] % 16 == 0 and K % 256 == 0:
             out = self.linear_decode(x2, x_mant_bits, epsilon) if (T <= 16 or self._tiled_ok()) else \
                 torch.cat([self.linear_decode(x2[i:i + 16], x_mant_bits, epsilon) for i in range(0, T, 16)], 0)
+        elif self.code_bits == 4 and native.hbfp_linear_mx8_ok(T, self.shape[0], K, self.mant_bits, x_mant_bits, self.block_size):
+            # prefill: both operands as e4m3 mantissas + E8M0 block scales on the block-scaled matrix instruction
+            # (exact block dot products, fp32 across blocks); the weight's image is made once per device
+            out = native.hbfp_linear_mx8(x2, *self._mx8_image(), x_mant_bits, epsilon, bias=bias)
+            return out.view(lead + (self.shape[0],))
         else:
             xq = _quantize_nm_ref_dtype(x2, 64, x_mant_bits, epsilon, rounding_modes.DETERM)
             out = F.linear(xq, self.dequantize().to(x.dtype))
         if bias is not None:
             out = out + bias
         return out.view(lead + (self.shape[0],))
+
+    def _mx8_image(self):
+        if getattr(self, "_mx8", None) is None or self._mx8[0].device != self.codes.device:
+            self._mx8 = native.mx8_from_hbfp(self.codes, self.exps, self.shape[-1], self.mant_bits, 4)
+        return self._mx8
 
     def save(self, path, compact24=False):
         """safetensors file: tensors `codes`, `exps`; the rest as string metadata.  compact24=True stores a 2:4-sparse

@@ -1,0 +1,241 @@
+// bfpq_mxgemm.hip -- prefill-sized consumer of the packed HBFP format: out[t][n] = sum_k x[t][k] W[n][k]
+// for many tokens, with BOTH operands in HBFP (<= 5 bits: mantissas in [-15, 15]) and block 64.
+//
+// HBFP is a block-scaled format with integer elements and a power-of-two scale per block -- which is what CDNA4's block-scaled
+// matrix instruction computes in hardware: v_mfma_scale_f32_32x32x64_f8f6f4 multiplies 32x64 by 64x32 elements and applies an
+// E8M0 (2^(s-127)) scale per 32 elements of K to each operand.  The mantissas -15..15 are exact in OCP e4m3 (4 significant
+// bits), K = 64 is exactly one HBFP block (both 32-halves carry the block's scale), so one instruction is the exact integer dot
+// product of a block times 2^(ew-mw) * 2^(ex-mx), accumulated in fp32 across blocks: the same arithmetic as the decode kernel
+// (bfpq_gemm.hip) at twice the bf16 matrix rate, with no per-block VALU work on the accumulators.  The reference runs F.linear
+// on the fake-quantised tensors (bfp_ops.py:187-190); the two agree up to fp32 summation order across blocks.
+//
+// Operand images ("mx8"): e4m3 bytes [rows, K] row-major + E8M0 scale bytes [rows, K/64], made from the packed codes and
+// exponents by k_mx8_from_codes (weights: once; activations: per call, 1 byte per element).
+//
+// Lane maps of the instruction, measured with one-hot operands (tools_dev/mxprobe): first operand lane l = row l&31 of D,
+// second operand lane l = column l&31; byte j of lane l of the first operand meets byte j of lane l of the second (so any k
+// order works if both sides use the same one); bytes 0-15 of lanes 0-31 and of lanes 32-63 form the first 32-block (scale taken
+// from lane row), bytes 16-31 the second (scale taken from lane row+32) -- with one HBFP block per instruction every lane simply
+// supplies its row's scale.  D: column = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+//
+// Structure: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 = 2x2 instruction tiles each), K step of
+// 128 bytes staged global -> LDS by 16-byte LDS-DMA (global_load_lds_dwordx4), LDS rows of 128 bytes with the 16-byte slot
+// XOR-swizzled by (row & 7) on the source address and on the read (conflict-free ds_read_b128), 32 KB of LDS and ~128 VGPRs so
+// that several workgroups per CU overlap each other's staging.  Workgroup ids are remapped so that the workgroups of one XCD
+// walk the token tiles of the same weight tile (the weight tile is fetched into that XCD's L2 once).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bfpq.h"
+#include "bfpq_common.h"
+
+using namespace bfpq;
+
+namespace {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 128;
+
+// e4m3 byte of an integer of magnitude m <= 15 (exact): 0, 1 = 0x38, then 0x38 + 4m (2..3), 0x40 + 2m (4..7), 0x48 + m (8..15)
+__device__ __forceinline__ uint32_t e4m3_of_mag(uint32_t m)
+{
+    const uint32_t v = m >= 8 ? 0x48u + m : (m >= 4 ? 0x40u + 2u * m : (m >= 2 ? 0x38u + 4u * m : 0x38u));
+    return m ? v : 0u;
+}
+__device__ __forceinline__ uint32_t e4m3_of_int(int c) { const uint32_t m = (uint32_t)(c < 0 ? -c : c); return e4m3_of_mag(m) | (c < 0 ? 0x80u : 0u); }
+
+// codes (4-bit two's complement nibbles, low nibble first, or int8) + int8 exponents -> e4m3 bytes + E8M0 scales
+// one thread = 8 elements
+template <int CODE_BITS>
+__global__ void __launch_bounds__(256) k_mx8_from_codes(const uint8_t* __restrict__ codes, const int8_t* __restrict__ exps, uint8_t* __restrict__ out8,
+                                                        uint8_t* __restrict__ outs, int64_t n_items, int64_t n_blocks, int mant_bits)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * 256) {
+        uint32_t lo = 0, hi = 0;
+        if constexpr (CODE_BITS == 4) {
+            const uint32_t w = reinterpret_cast<const uint32_t*>(codes)[i];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int c = (int)((w >> (4 * j)) & 15u);
+                const uint32_t b = e4m3_of_int(c >= 8 ? c - 16 : c);
+                if (j < 4) lo |= b << (8 * j); else hi |= b << (8 * (j - 4));
+            }
+        } else {
+            const uint2 w = reinterpret_cast<const uint2*>(codes)[i];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                lo |= e4m3_of_int((int)(int8_t)(w.x >> (8 * j))) << (8 * j);
+                hi |= e4m3_of_int((int)(int8_t)(w.y >> (8 * j))) << (8 * j);
+            }
+        }
+        reinterpret_cast<uint2*>(out8)[i] = make_uint2(lo, hi);
+        if (i < n_blocks) {                                 // the first n_blocks threads also translate the exponents
+            const int e = exps[i];
+            int s = e - mant_bits + 127;
+            s = s < 0 ? 0 : (s > 254 ? 254 : s);
+            outs[i] = e == -128 ? 0xffu : (uint8_t)s;       // -128 marks a NaN block: E8M0 0xff is NaN
+        }
+    }
+}
+
+__device__ __forceinline__ v8i read_frag(const uint8_t* tile, int row, int c)       // 32 bytes: 16-byte slots c, c+1 of the row
+{
+    const int sw = row & 7;
+    const v4i a0 = *reinterpret_cast<const v4i*>(tile + row * BK + ((c ^ sw) << 4));
+    const v4i a1 = *reinterpret_cast<const v4i*>(tile + row * BK + (((c + 1) ^ sw) << 4));
+    return v8i{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+}
+
+template <int OP>
+__device__ __forceinline__ void block_mfma(const uint8_t* sA, const uint8_t* sB, int b, int rowA, int rowB, int half, v16f (&acc)[2][2],
+                                           const int (&sa)[2], const int (&sb)[2])
+{
+    const int c = b * 4 + half * 2;
+    v8i aF[2], bF[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) { aF[i] = read_frag(sA, rowA + 32 * i, c); bF[i] = read_frag(sB, rowB + 32 * i, c); }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aF[i], bF[j], acc[i][j], 0, 0, OP, sa[i], OP, sb[j]);
+}
+
+template <int OUT_DT>
+__global__ void __launch_bounds__(256) k_mx8_gemm(const uint8_t* __restrict__ x8, const uint8_t* __restrict__ xs, const uint8_t* __restrict__ w8,
+                                                  const uint8_t* __restrict__ wsc, const void* __restrict__ bias, void* __restrict__ out,
+                                                  int T, int N, int K, int tiles_t)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[(BM + BN) * BK];
+    uint8_t* const sA = lds;
+    uint8_t* const sB = lds + BM * BK;
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    // workgroups that share an XCD (id % 8) get consecutive tile numbers: token tiles fastest, so they share a weight tile
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int t0 = (wg % tiles_t) * BM, n0 = (wg / tiles_t) * BN;
+    const int nb = K >> 6;                                           // blocks per row = scale bytes per row
+
+    // staging: instruction i of wave w fills LDS rows (4i+w)*8 .. +7 (1 KB, lane-linear); lane l = row l>>3, slot l&7 holds
+    // the row's 16-byte piece slot ^ (row & 7)
+    size_t offA[4], offB[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = (4 * i + w) * 8 + (l >> 3), piece = ((l & 7) ^ (row & 7)) << 4;
+        const int ta = t0 + row < T ? t0 + row : T - 1, na = n0 + row < N ? n0 + row : N - 1;     // rows past the edge repeat the last row
+        offA[i] = (size_t)ta * K + piece;
+        offB[i] = (size_t)na * K + piece;
+    }
+    const int wr = w >> 1, wc = w & 1, half = l >> 5;
+    const int rowA = wr * 64 + (l & 31), rowB = wc * 64 + (l & 31);
+    const uint32_t* sxp[2];
+    const uint32_t* swp[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int ta = t0 + rowA + 32 * i < T ? t0 + rowA + 32 * i : T - 1, na = n0 + rowB + 32 * i < N ? n0 + rowB + 32 * i : N - 1;
+        sxp[i] = reinterpret_cast<const uint32_t*>(xs + (size_t)ta * nb);
+        swp[i] = reinterpret_cast<const uint32_t*>(wsc + (size_t)na * nb);
+    }
+    v16f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    auto stage = [&](int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x8 + offA[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(sA + (4 * i + w) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w8 + offB[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(sB + (4 * i + w) * 1024), 16, 0, 0);
+        }
+    };
+
+    for (int k0 = 0; k0 < K; k0 += 2 * BK) {                         // 4 blocks per trip: one scale dword per operand row
+        int sa[2], sb[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) { sa[i] = (int)sxp[i][k0 >> 8]; sb[i] = (int)swp[i][k0 >> 8]; }
+        stage(k0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        block_mfma<0>(sA, sB, 0, rowA, rowB, half, acc, sa, sb);
+        block_mfma<1>(sA, sB, 1, rowA, rowB, half, acc, sa, sb);
+        __syncthreads();
+        stage(k0 + BK);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        block_mfma<2>(sA, sB, 0, rowA, rowB, half, acc, sa, sb);
+        block_mfma<3>(sA, sB, 1, rowA, rowB, half, acc, sa, sb);
+        __syncthreads();
+    }
+
+    // epilogue: D column = lane & 31 (n), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (t)
+    using raw_t = typename Traits<OUT_DT>::raw_t;
+    raw_t* const o = reinterpret_cast<raw_t*>(out);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int n = n0 + wc * 64 + 32 * j + (l & 31);
+        if (n >= N) continue;
+        const float bv = bias ? raw_to_f32<OUT_DT>((uint32_t)reinterpret_cast<const raw_t*>(bias)[n]) : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int t = t0 + wr * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (t < T) o[(size_t)t * N + n] = (raw_t)f32_to_raw<OUT_DT>(acc[i][j][e] + bv);
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bfpq_mx8_from_hbfp(const void* codes, const int8_t* exps, void* out8, void* out_scale, int64_t rows, int64_t cols,
+                       int code_bits, int mant_bits, void* stream)
+{
+    if (rows < 0 || cols < 0 || (code_bits != 4 && code_bits != 8) || mant_bits < 1 || mant_bits > 4 || cols % 64 != 0) return BFPQ_E_ARG;
+    if (code_bits == 4 && mant_bits > 3) return BFPQ_E_ARG;
+    if (rows * cols == 0) return 0;
+    if (!codes || !exps || !out8 || !out_scale) return BFPQ_E_ARG;
+    const int64_t n_items = rows * cols / 8, n_blocks = rows * cols / 64;
+    int64_t g = (n_items + 255) / 256;
+    if (g > 8192) g = 8192;
+    hipStream_t s = (hipStream_t)stream;
+    if (code_bits == 4) hipLaunchKernelGGL((k_mx8_from_codes<4>), dim3((unsigned)g), dim3(256), 0, s, (const uint8_t*)codes, exps, (uint8_t*)out8, (uint8_t*)out_scale, n_items, n_blocks, mant_bits);
+    else hipLaunchKernelGGL((k_mx8_from_codes<8>), dim3((unsigned)g), dim3(256), 0, s, (const uint8_t*)codes, exps, (uint8_t*)out8, (uint8_t*)out_scale, n_items, n_blocks, mant_bits);
+    return (int)hipGetLastError();
+}
+
+int bfpq_hbfp_linear_mx8_ok(int64_t T, int64_t N, int64_t K)
+{
+    return T >= 1 && N >= 1 && K >= 256 && K % 256 == 0 && T * K < ((int64_t)1 << 40) && N * K < ((int64_t)1 << 40) &&
+           ((T + BM - 1) / BM) * ((N + BN - 1) / BN) < ((int64_t)1 << 30);
+}
+
+int bfpq_hbfp_linear_mx8(const void* x8, const void* xs, const void* w8, const void* ws, const void* bias, void* out,
+                         int64_t T, int64_t N, int64_t K, int out_dtype, void* stream)
+{
+    if (out_dtype < 0 || out_dtype > 2 || T < 0 || N < 0) return BFPQ_E_ARG;
+    if (T == 0 || N == 0) return 0;
+    if (!bfpq_hbfp_linear_mx8_ok(T, N, K)) return BFPQ_E_UNSUPPORTED;
+    if (!x8 || !xs || !w8 || !ws || !out) return BFPQ_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(x8) | reinterpret_cast<uintptr_t>(w8)) & 15u) return BFPQ_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(xs) | reinterpret_cast<uintptr_t>(ws)) & 3u) return BFPQ_E_ARG;
+    const int tiles_t = (int)((T + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
+    const dim3 grid((unsigned)(tiles_t * tiles_n));
+    hipStream_t s = (hipStream_t)stream;
+    const uint8_t *a = (const uint8_t*)x8, *as = (const uint8_t*)xs, *b = (const uint8_t*)w8, *bs = (const uint8_t*)ws;
+    if (out_dtype == BFPQ_F32) hipLaunchKernelGGL((k_mx8_gemm<BFPQ_F32>), grid, dim3(256), 0, s, a, as, b, bs, bias, out, (int)T, (int)N, (int)K, tiles_t);
+    else if (out_dtype == BFPQ_F16) hipLaunchKernelGGL((k_mx8_gemm<BFPQ_F16>), grid, dim3(256), 0, s, a, as, b, bs, bias, out, (int)T, (int)N, (int)K, tiles_t);
+    else hipLaunchKernelGGL((k_mx8_gemm<BFPQ_BF16>), grid, dim3(256), 0, s, a, as, b, bs, bias, out, (int)T, (int)N, (int)K, tiles_t);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -93,16 +93,20 @@ def load_library():
         L.bfpq_hbfp_linear_decode.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
         L.bfpq_hbfp_linear_tiled_ok.argtypes = [i64, i64]
         L.bfpq_hbfp_linear_decode_tiled.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
+        L.bfpq_mx8_from_hbfp.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, vp]
+        L.bfpq_hbfp_linear_mx8_ok.argtypes = [i64, i64, i64]
+        L.bfpq_hbfp_linear_mx8.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]
         for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_is_fused", "bfpq_nm_sparsify",
                      "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
                      "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize", "bfpq_hbfp_linear_slices",
-                     "bfpq_hbfp_linear_decode", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled"):
+                     "bfpq_hbfp_linear_decode", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled",
+                     "bfpq_mx8_from_hbfp", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8"):
             getattr(L, name).restype = i32
         _lib = L
         return _lib
 
 
-EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_select_ws_bytes", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24",
+EXPORTED_SYMBOLS = ("bfpq_mx8_from_hbfp", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_select_ws_bytes", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_is_fused", "bfpq_nm_sparsify",
                     "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
                     "bfpq_threshold_apply", "bfpq_quantize_threshold")
@@ -641,4 +645,49 @@ def hbfp_linear_decode(x, wcodes, wexps, w_mant_bits, x_mant_bits=7, epsilon=1e-
         check(L.bfpq_hbfp_linear_decode(_ptr(wcodes.contiguous()), _ptr(wexps.contiguous()), _ptr(xc16), _ptr(xe16), _ptr(out),
                                         _ptr(slabs), T, N, K, DTYPE_CODE[out_dtype], int(w_mant_bits), int(x_mant_bits), _stream(x)),
               "bfpq_hbfp_linear_decode")
+    return out.view(tuple(x.shape[:-1]) + (N,))
+
+
+def mx8_from_hbfp(codes, exps, cols, mant_bits, code_bits):
+    """packed HBFP (codes + int8 exponents, block 64, mantissas <= 4 bits) -> the operand image of the block-scaled matrix
+    instruction: e4m3 bytes [rows, cols] + E8M0 scale bytes [rows, cols/64] (bfpq_mx8_from_hbfp)"""
+    require_device_tensor_any(codes)
+    L = load_library()
+    rows = exps.numel() // (cols // 64)
+    dev = codes.device
+    with torch.cuda.device(dev):
+        o8 = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
+        osc = torch.empty((rows, cols // 64), dtype=torch.uint8, device=dev)
+        check(L.bfpq_mx8_from_hbfp(_ptr(codes.contiguous()), _ptr(exps.contiguous()), _ptr(o8), _ptr(osc), rows, cols, int(code_bits), int(mant_bits),
+                                   torch.cuda.current_stream(dev).cuda_stream), "bfpq_mx8_from_hbfp")
+    return o8, osc
+
+
+def hbfp_linear_mx8_ok(T, N, K, w_mant_bits, x_mant_bits, block_size=64):
+    return block_size == 64 and 1 <= w_mant_bits <= 4 and 1 <= x_mant_bits <= 4 and bool(load_library().bfpq_hbfp_linear_mx8_ok(T, N, K))
+
+
+def hbfp_linear_mx8(x, w8, wscale, x_mant_bits, epsilon=1e-8, bias=None, out_dtype=None):
+    """out = Q(x) @ W^T (+ bias) for any number of tokens on the block-scaled matrix instruction: x is quantized to
+    HBFP(x_mant_bits + 1) block 64 (int8 codes + exponents), turned into its e4m3 / E8M0 image and multiplied with the
+    weight's image (mx8_from_hbfp of the packed weight, made once)."""
+    require_device_tensor(x)
+    L = load_library()
+    K = x.shape[-1]
+    T = x.numel() // K
+    N = w8.shape[0]
+    if not hbfp_linear_mx8_ok(T, N, K, 1, x_mant_bits):
+        raise ValueError(f"hbfp_linear_mx8 needs K % 256 == 0 and activation mantissas of <= 4 bits (got T={T}, N={N}, K={K}, x_mant_bits={x_mant_bits})")
+    dev = x.device
+    out_dtype = out_dtype or x.dtype
+    with torch.cuda.device(dev):
+        xc = torch.empty((T, K), dtype=torch.int8, device=dev)
+        xe = torch.empty((T, K // 64), dtype=torch.int8, device=dev)
+        quantize_nm(x.reshape(T, K), 64, x_mant_bits, epsilon, want_deq=False, code_bits=8, want_exp=True, codes_out=xc, exps_out=xe)
+        x8, xs = mx8_from_hbfp(xc, xe, K, x_mant_bits, 8)
+        out = torch.empty((T, N), dtype=out_dtype, device=dev)
+        if bias is not None:
+            bias = bias.to(out_dtype).contiguous()
+        check(L.bfpq_hbfp_linear_mx8(_ptr(x8), _ptr(xs), _ptr(w8), _ptr(wscale), _ptr(bias) if bias is not None else None, _ptr(out),
+                                     T, N, K, DTYPE_CODE[out_dtype], _stream(x)), "bfpq_hbfp_linear_mx8")
     return out.view(tuple(x.shape[:-1]) + (N,))

@@ -726,6 +726,45 @@ def test_packed_consumer_decode_linear(N, K, T, dname):
             native.load_library().bfpq_tune(1, 0)
 
 
+@pytest.mark.parametrize("N,K,T,dname", [(256, 512, 200, "bf16"), (384, 768, 129, "bf16"), (1024, 1024, 300, "f16"), (200, 256, 1, "f32"),
+                                          (4096, 4096, 512, "bf16")])
+def test_packed_consumer_prefill_mx8(N, K, T, dname):
+    """§8f next #3, prefill: out = Q(x) @ Q(W)^T for many tokens from the packed weight on the block-scaled matrix
+    instruction (e4m3 mantissas + E8M0 block scales: exact block dot products, fp32 across blocks), against the same product of
+    the two fake-quantised tensors in fp64.  Ragged T and N (tiles past the edge), bias, HBFP4 and HBFP5 activations."""
+    dt = DT[dname]
+    w = synth(N, K, dt).to(DEV)
+    x = synth(T, K, dt, 1.0, seed=9).to(DEV)
+    x[0, :64] = 0                                                     # a zero block (exponent -26, all-zero mantissas)
+    x[T - 1, 64:128] *= 4096                                          # and a block on a very different scale
+    bias = synth(1, N, dt, 1.0, seed=3).to(DEV).view(N)
+    pw = bfp_ops.PackedBFP.quantize(w, 3, 64, N=2, M=4)
+    wq = pw.dequantize().double().cpu()
+    w8, wsc = native.mx8_from_hbfp(pw.codes, pw.exps, K, 3, 4)
+    for xm in (3, 4):
+        assert native.hbfp_linear_mx8_ok(T, N, K, 3, xm)
+        xq = bfp_ops.float_to_bfp_blocked(x, **cfg(mant_bits=xm, block_size=64), identifier='in').double().cpu()
+        want = xq @ wq.t()
+        got32 = native.hbfp_linear_mx8(x, w8, wsc, xm, out_dtype=torch.float32)
+        assert got32.shape == (T, N)
+        g = got32.double().cpu()
+        nan = torch.isnan(want)                                      # fp16: the zero block is a NaN block in the reference (A.2) -> NaN row
+        assert torch.equal(torch.isnan(g), nan) and bool(nan.any()) == (dname == "f16")
+        err32 = (g - want)[~nan].abs().max() / want[~nan].abs().max()
+        assert float(err32) < 2e-6, (xm, float(err32))              # only the fp32 accumulation order across blocks differs
+    # through the module-level entry point, with bias, in the tensor's dtype
+    got = pw.linear(x, bias, x_mant_bits=3, decode_tokens=0)
+    assert got.shape == (T, N) and got.dtype == dt
+    xq = bfp_ops.float_to_bfp_blocked(x, **cfg(mant_bits=3, block_size=64), identifier='in').double().cpu()
+    want = xq @ wq.t() + bias.double().cpu()
+    nan = torch.isnan(want)
+    err = (got.double().cpu() - want)[~nan].abs().max() / want[~nan].abs().max()
+    tol = {"f32": 2e-6, "bf16": 6e-3, "f16": 8e-4}[dname]
+    assert float(err) < tol and torch.equal(torch.isnan(got.cpu()), nan), (float(err), tol)
+    # 8-bit activations do not fit e4m3: the entry point must take the decode-and-library route, not a wrong product
+    assert not native.hbfp_linear_mx8_ok(T, N, K, 3, 7)
+
+
 def test_dist_paths_with_the_native_engine_on_rccl():
     """dist.py end to end on the device with the HIP engine and RCCL (backend "nccl"), one rank: the gloo tests cover the
     multi-rank protocol with a stand-in engine, this covers the real kernels, streams and collectives behind the same
