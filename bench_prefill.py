@@ -29,6 +29,7 @@ def timeit(fn, iters=20, rounds=5):
 
 def main():
     dev = "cuda:0"
+    native.SHARE_ACT_IMAGE = False          # the loop re-uses one input tensor: every call must quantize it, as a first projection does
     rows = []
     cfg = bfpq.BFPConfig.hbfp(4, 64, w_sparsity=True, N=2, M=4, sparsity_mode='structured', first='s').to_kwargs()
     shapes = (("q_proj", 2048, 4096, 4096), ("gate_proj", 2048, 4096, 11008), ("down_proj", 2048, 11008, 4096),
@@ -47,10 +48,7 @@ def main():
             packed = timeit(lambda: pw.linear(x, x_mant_bits=3))
             # the matrix kernel alone, operands prepared
             w8, wsc = pw._mx8_image()
-            xc = torch.empty((tokens, fin), dtype=torch.int8, device=dev)
-            xe = torch.empty((tokens, fin // 64), dtype=torch.int8, device=dev)
-            native.quantize_nm(x, 64, 3, 1e-8, want_deq=False, code_bits=8, want_exp=True, codes_out=xc, exps_out=xe)
-            x8, xs = native.mx8_from_hbfp(xc, xe, fin, 3, 8)
+            x8, xs = native.quantize_mx8(x, 3)
             out = torch.empty((tokens, fout), dtype=torch.bfloat16, device=dev)
             L = native.load_library()
             st = torch.cuda.current_stream().cuda_stream
@@ -59,11 +57,10 @@ def main():
                 native.check(L.bfpq_hbfp_linear_mx8(x8.data_ptr(), xs.data_ptr(), w8.data_ptr(), wsc.data_ptr(), None, out.data_ptr(),
                                                    tokens, fout, fin, 2, torch.cuda.current_stream().cuda_stream), "mx8")
             gemm = timeit(gemm_only)
-            aq = timeit(lambda: native.quantize_nm(x, 64, 3, 1e-8, want_deq=False, code_bits=8, want_exp=True, codes_out=xc, exps_out=xe))
-            cv = timeit(lambda: native.mx8_from_hbfp(xc, xe, fin, 3, 8))
+            aq = timeit(lambda: native.quantize_mx8(x, 3))
         flop = 2.0 * tokens * fin * fout
         rows.append(dict(layer=name, tokens=tokens, in_features=fin, out_features=fout, f_linear_us=plain, bfplinear_cached_us=cached,
-                         packed_prefill_us=packed, mx8_gemm_us=gemm, act_codes_us=aq, act_image_us=cv,
+                         packed_prefill_us=packed, mx8_gemm_us=gemm, act_image_us=aq,
                          f_linear_tflops=flop / plain / 1e6, mx8_gemm_tflops=flop / gemm / 1e6))
         print(rows[-1], flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

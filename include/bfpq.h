@@ -48,6 +48,7 @@ int bfpq_version(void);
 /* process-wide tuning knobs (measurement aid; defaults are the measured optimum on MI355X) */
 #define BFPQ_TUNE_MAX_GRID 0       /* cap on workgroups of the streaming kernels (default 1024) */
 #define BFPQ_TUNE_GEMM_ROW_TILES 1 /* 16-row tiles per wave in bfpq_hbfp_linear_decode_tiled: 0 = choose (default), 1, 2, 4 */
+#define BFPQ_TUNE_MX8_VARIANT 2    /* tile shape of bfpq_hbfp_linear_mx8: -1 = choose (default), 0..2 force (A/B measurements) */
 int bfpq_tune(int key, int value);
 const char* bfpq_error_string(int code);
 
@@ -236,6 +237,11 @@ int bfpq_hbfp_linear_decode_tiled(const void* wtiles_dev, const void* wexpt_dev,
  * bias (nullable) and out of out_dtype. */
 int bfpq_mx8_from_hbfp(const void* codes_dev, const int8_t* exp_dev, void* out8_dev, void* out_scale_dev, int64_t rows, int64_t cols,
                        int code_bits, int mant_bits, void* stream);
+/* a 16-bit tensor straight to its mx8 image (dense HBFP quantize, block 64, round-half-even: the activation operand of a
+ * prefill; one pass, 2 B read + 1.016 B written per element).  fp32 tensors / cols % 64 != 0 / unaligned pointers: BFPQ_E_UNSUPPORTED
+ * (take bfpq_quantize_nm with int8 codes + bfpq_mx8_from_hbfp). */
+int bfpq_quantize_mx8(const void* in_dev, void* out8_dev, void* out_scale_dev, int64_t rows, int64_t cols, int dtype, int mant_bits,
+                      double epsilon, const uint8_t* exp_win_dev, void* stream);
 int bfpq_hbfp_linear_mx8_ok(int64_t T, int64_t N, int64_t K);   /* 1 when the kernel applies */
 int bfpq_hbfp_linear_mx8(const void* x8_dev, const void* xscale_dev, const void* w8_dev, const void* wscale_dev, const void* bias_dev,
                          void* out_dev, int64_t T, int64_t N, int64_t K, int out_dtype, void* stream);

@@ -142,6 +142,9 @@ BFPQ_HIDDEN int fused_launch_2(const FusedArgs& a, int M, bool sfirst, hipStream
 BFPQ_HIDDEN int fused_threshold_0(const FusedArgs& a, hipStream_t s);
 BFPQ_HIDDEN int fused_threshold_1(const FusedArgs& a, hipStream_t s);
 BFPQ_HIDDEN int fused_threshold_2(const FusedArgs& a, hipStream_t s);
+BFPQ_HIDDEN int fused_mx8_0(const FusedArgs& a, hipStream_t s);
+BFPQ_HIDDEN int fused_mx8_1(const FusedArgs& a, hipStream_t s);
+BFPQ_HIDDEN int fused_mx8_2(const FusedArgs& a, hipStream_t s);
 BFPQ_HIDDEN int fused_batched_0(const FusedArgs& a, const BatchArgs& b, int M, bool sfirst, hipStream_t s);
 BFPQ_HIDDEN int fused_batched_1(const FusedArgs& a, const BatchArgs& b, int M, bool sfirst, hipStream_t s);
 BFPQ_HIDDEN int fused_batched_2(const FusedArgs& a, const BatchArgs& b, int M, bool sfirst, hipStream_t s);
@@ -152,6 +155,10 @@ inline int fused_launch(int dtype, const FusedArgs& a, int M, bool sfirst, hipSt
 inline int fused_threshold(int dtype, const FusedArgs& a, hipStream_t s)
 {
     return dtype == BFPQ_F32 ? fused_threshold_0(a, s) : (dtype == BFPQ_F16 ? fused_threshold_1(a, s) : fused_threshold_2(a, s));
+}
+inline int fused_mx8(int dtype, const FusedArgs& a, hipStream_t s)
+{
+    return dtype == BFPQ_F32 ? fused_mx8_0(a, s) : (dtype == BFPQ_F16 ? fused_mx8_1(a, s) : fused_mx8_2(a, s));
 }
 inline int fused_batched(int dtype, const FusedArgs& a, const BatchArgs& b, int M, bool sfirst, hipStream_t s)
 {

@@ -17,11 +17,13 @@ namespace bfpq_dev {
 //   wider than the dtype) makes the whole wavefront replay that item through the step-by-step
 //   emulation (quant_elem); the branch is wave-uniform and never taken on ordinary weights.
 // ---------------------------------------------------------------------------------------------
-template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY, bool BATCHED, bool F32IMG = false, bool PACK4 = false>
+template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY, bool BATCHED, bool F32IMG = false, int PACK = 0>
 __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unused]] const BatchArgs* b)
 {
     using T = Traits<DT>;
     constexpr int VEC = T::VEC;
+    constexpr bool PACK4 = PACK != 0;                            // packed-only output: 4-bit codes + int8 exponents (PACK == 4) or
+    constexpr bool MX8 = PACK == 8;                              // e4m3 mantissas + E8M0 block scales (PACK == 8: the matrix unit's image)
     __shared__ __attribute__((aligned(16))) uint8_t s_win[512];
     __shared__ uint2 s_mask[NM == 4 && VEC == 8 ? 736 : 1];      // 16-bit dtypes: AND masks for the two dwords of a group
     __shared__ uint8_t s_keep[NM == 4 && VEC == 4 ? 736 : 1];    // fp32: 4-bit keep mask
@@ -242,7 +244,7 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
         for (int j = 0; j < VEC; j++) code[j] = 0.f;
         int e_blk = 0;
         bool nan_blk = false;
-        [[maybe_unused]] uint32_t pack_w = 0;                     // PACK4: the item's eight 4-bit codes, the block's exponent byte
+        [[maybe_unused]] uint32_t pack_w = 0, pack_w2 = 0;        // PACK4: the item's eight 4-bit codes (MX8: eight e4m3 bytes), the block's exponent byte
         [[maybe_unused]] int pack_e = 0;
         [[maybe_unused]] bool pack_hot = false;
         if (do_quant) {
@@ -285,6 +287,19 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
                         q[x] = __builtin_amdgcn_perm(f2u(v.y), f2u(v.x), 0x05040100u);             // (q_hi << 16) | q_lo
                     }
                     if constexpr (NM != 0 && !SFIRST) nm_mask(q[0], q[1], q[2], q[3]);   // Q before S: inside a block codes order like values
+                    if constexpr (MX8) {
+                        // e4m3 byte of an integer magnitude m: one v_perm into an 8-byte table (m <= 7), 0x48 + m above;
+                        // the sign bits are the high bytes of the input halves
+                        auto img = [&](uint32_t qa, uint32_t qb, uint32_t da, uint32_t db) __attribute__((always_inline)) {
+                            const uint32_t m = __builtin_amdgcn_perm(qb, qa, 0x06040200u) & 0x0f0f0f0fu;
+                            uint32_t e = __builtin_amdgcn_perm(0x4e4c4a48u, 0x44403800u, m & 0x07070707u);
+                            if (a.mant_bits > 3) e = bfi_b32(((m >> 3) & 0x01010101u) * 0xffu, m + 0x48484848u, e);
+                            return e | (__builtin_amdgcn_perm(db, da, 0x07050301u) & 0x80808080u);
+                        };
+                        pack_w = img(q[0], q[1], dd[0], dd[1]);
+                        pack_w2 = img(q[2], q[3], dd[2], dd[3]);
+                        pack_e = h16.e;
+                    } else {
                     uint32_t c[4];
 #pragma unroll
                     for (int x = 0; x < 4; x++) {
@@ -297,6 +312,7 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
                     p0 |= p0 >> 4; p1 |= p1 >> 4;                                                  // bytes 0 and 2 now hold two nibbles each
                     pack_w = __builtin_amdgcn_perm(p1, p0, 0x06040200u);
                     pack_e = h16.e;
+                    }
                 } else if constexpr (VEC == 8 && !STOCH && DEQ_ONLY) {
                     const uint32_t absm = T::ABS | (T::ABS << 16);
                     const uint32_t dd[4] = {d0, d1, d2, d3};
@@ -409,14 +425,29 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
             // hipcc drain the memory queue at the loop top): every lane its code dword, and the wave's eight exponent bytes as
             // ONE 8-byte value that all lanes write to the same address
             if (!pack_hot) {
-                uint32_t w = 0;
+                if constexpr (MX8) {
+                    auto b8 = [](float cf) { const int c = (int)cf; const uint32_t m = (uint32_t)(c < 0 ? -c : c);
+                                             const uint32_t v = m >= 8 ? 0x48u + m : (m >= 4 ? 0x40u + 2u * m : (m >= 2 ? 0x38u + 4u * m : 0x38u));
+                                             return (m ? v : 0u) | (c < 0 ? 0x80u : 0u); };
+                    pack_w = pack_w2 = 0;
 #pragma unroll
-                for (int j = 0; j < VEC; j++) w |= ((uint32_t)(int)code[j] & 0xfu) << (4 * j);
-                pack_w = w;
-                pack_e = nan_blk ? -128 : (e_blk < -127 ? -127 : (e_blk > 127 ? 127 : e_blk));
+                    for (int j = 0; j < 4; j++) { pack_w |= b8(code[j]) << (8 * j); pack_w2 |= b8(code[(4 + j) % VEC]) << (8 * j); }
+                    pack_e = e_blk;
+                } else {
+                    uint32_t w = 0;
+#pragma unroll
+                    for (int j = 0; j < VEC; j++) w |= ((uint32_t)(int)code[j] & 0xfu) << (4 * j);
+                    pack_w = w;
+                    pack_e = nan_blk ? -128 : (e_blk < -127 ? -127 : (e_blk > 127 ? 127 : e_blk));
+                }
+            }
+            if constexpr (MX8) {                                  // E8M0 scale of the block: 2^(e - mant_bits), NaN block -> 0xff
+                const int sc = pack_e - a.mant_bits + 127;
+                pack_e = (!pack_hot && nan_blk) ? 0xff : (sc < 0 ? 0 : (sc > 254 ? 254 : sc));
             }
             if constexpr (!GUARD) {
-                reinterpret_cast<uint32_t*>(a.out_codes)[item] = pack_w;
+                if constexpr (MX8) reinterpret_cast<uint2*>(a.out_codes)[item] = make_uint2(pack_w, pack_w2);
+                else reinterpret_cast<uint32_t*>(a.out_codes)[item] = pack_w;
                 const int e8 = pack_e & 0xff;
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(e8, 0) | ((uint32_t)__builtin_amdgcn_readlane(e8, 8) << 8) |
                                     ((uint32_t)__builtin_amdgcn_readlane(e8, 16) << 16) | ((uint32_t)__builtin_amdgcn_readlane(e8, 24) << 24);
@@ -425,7 +456,8 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
                 const int64_t tile0 = uniform64(item - (threadIdx.x & 63));
                 *reinterpret_cast<uint2*>(a.out_exp + (tile0 >> 3)) = make_uint2(lo, hi);
             } else if (valid) {
-                reinterpret_cast<uint32_t*>(a.out_codes)[item] = pack_w;
+                if constexpr (MX8) reinterpret_cast<uint2*>(a.out_codes)[item] = make_uint2(pack_w, pack_w2);
+                else reinterpret_cast<uint32_t*>(a.out_codes)[item] = pack_w;
                 if ((item & 7) == 0) a.out_exp[item >> 3] = (int8_t)pack_e;
             }
             return;
@@ -705,10 +737,10 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
     asm volatile("" : : "v"(dummy));                                       // the dummy's only "use": after all the work
 }
 
-template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY, bool F32IMG = false, bool PACK4 = false>
+template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY, bool F32IMG = false, int PACK = 0>
 __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
 {
-    fused_flat_body<DT, NM, SFIRST, STOCH, LPBT, DEQ_ONLY, false, F32IMG, PACK4>(a, nullptr);
+    fused_flat_body<DT, NM, SFIRST, STOCH, LPBT, DEQ_ONLY, false, F32IMG, PACK>(a, nullptr);
 }
 
 // the same item pipeline over a list of tensors (drop-in mode, round-half-even, dense or N:4)
@@ -772,7 +804,7 @@ int launch_fused_l(const FusedArgs& a, hipStream_t s)
         // packed 4-bit codes + exponents only, block = 8 lane items: the lean packed instantiation
         if (!a.out_deq && a.out_codes && a.code_bits == 4 && a.out_exp && a.lpb == 8 && (reinterpret_cast<uintptr_t>(a.out_exp) & 7u) == 0) {
             const dim3 grid(grid_for(a.n_items)), block(kThreads);
-            hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, false, 8, false, false, true>), grid, block, 0, s, a);
+            hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, false, 8, false, false, 4>), grid, block, 0, s, a);
             return (int)hipGetLastError();
         }
     }
@@ -784,6 +816,17 @@ int launch_fused_l(const FusedArgs& a, hipStream_t s)
         }
     }
     return launch_fused_o<DT, NM, SFIRST, STOCH, false>(a, s);
+}
+
+// dense quantize of a 16-bit tensor straight into the block-scaled matrix unit's operand image (e4m3 + E8M0), block = 8 lane items
+template <int DT>
+int launch_fused_mx8(const FusedArgs& a, hipStream_t s)
+{
+    if constexpr (Traits<DT>::VEC == 8) {
+        const dim3 grid(grid_for(a.n_items)), block(kThreads);
+        hipLaunchKernelGGL((k_fused_flat<DT, 0, true, false, 8, false, false, 8>), grid, block, 0, s, a);
+        return (int)hipGetLastError();
+    } else return BFPQ_E_UNSUPPORTED;
 }
 
 template <int DT>

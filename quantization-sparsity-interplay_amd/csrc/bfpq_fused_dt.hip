@@ -15,6 +15,7 @@ namespace bfpq_dev {
 
 int BFPQ_CAT(fused_launch_, BFPQ_FUSED_DT)(const FusedArgs& a, int M, bool sfirst, hipStream_t s) { return launch_fused<BFPQ_FUSED_DT>(a, M, sfirst, s); }
 int BFPQ_CAT(fused_threshold_, BFPQ_FUSED_DT)(const FusedArgs& a, hipStream_t s) { return launch_fused_threshold<BFPQ_FUSED_DT>(a, s); }
+int BFPQ_CAT(fused_mx8_, BFPQ_FUSED_DT)(const FusedArgs& a, hipStream_t s) { return launch_fused_mx8<BFPQ_FUSED_DT>(a, s); }
 int BFPQ_CAT(fused_batched_, BFPQ_FUSED_DT)(const FusedArgs& a, const BatchArgs& b, int M, bool sfirst, hipStream_t s)
 {
     return launch_batched_dt<BFPQ_FUSED_DT>(a, b, M, sfirst, s);

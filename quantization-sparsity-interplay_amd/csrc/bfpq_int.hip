@@ -47,46 +47,6 @@ __device__ __forceinline__ float int_q(float x, float scale, float zero, float m
     return scale * (q - zero);                             //                                      :8
 }
 
-// The division of int_q without dividing.  t = x * fl(1 / scale) lies within 2 ulp of the correctly rounded quotient d, so
-// rint(t) == rint(d) whenever t is farther than that from a half-integer; a lane that cannot show this (near a tie, NaN,
-// a quotient too large for the margin, a scale or reciprocal that is not a normal number) raises `bad`, and the caller
-// redoes the wave's item with the true division (int_q).  Everything after the rint is the reference's own op sequence.
-struct IntScale { float scale, inv; bool ok; };
-__device__ __forceinline__ IntScale int_scale_inv(float scale)
-{
-    IntScale s;
-    s.scale = scale;
-    s.inv = 1.0f / scale;
-    const uint32_t es = (f2u(scale) >> 23) & 0xffu, ei = (f2u(s.inv) >> 23) & 0xffu;
-    s.ok = es != 0u && es != 0xffu && ei != 0u && ei != 0xffu;
-    return s;
-}
-__device__ __forceinline__ float int_q_fast(float x, const IntScale& s, float zero, float maxq, bool& bad)
-{
-    const float t = x * s.inv;
-    const float r = rintf(t);
-    const float f = fabsf(t - r);
-    bad |= !(f + fabsf(t) * 4.8e-7f < 0.5f);               // (false for NaN; |t| >= 2^20 fails it by construction)
-    float q = r + zero;
-    q = fminf(fmaxf(q, 0.0f), maxq);                       // (no NaN on this path)
-    return s.scale * (q - zero);
-}
-// VEC elements of one channel / VEC adjacent channels: the fast form, redone exactly when any lane of the wave asks for it
-template <int VEC, bool PER_ELEM>
-__device__ __forceinline__ void int_q_vec(float* v, const IntScale* sc, float zero, float maxq)
-{
-    float o[VEC];
-    bool bad = false;
-#pragma unroll
-    for (int j = 0; j < VEC; j++) { const IntScale& s = sc[PER_ELEM ? j : 0]; bad |= !s.ok; o[j] = int_q_fast(v[j], s, zero, maxq, bad); }
-    if (__builtin_expect(__any(bad), 0)) {
-#pragma unroll
-        for (int j = 0; j < VEC; j++) o[j] = int_q(v[j], sc[PER_ELEM ? j : 0].scale, zero, maxq);
-    }
-#pragma unroll
-    for (int j = 0; j < VEC; j++) v[j] = o[j];
-}
-
 template <int DT> __device__ __forceinline__ float ldf(const void* in, int64_t i)
 {
     using raw_t = typename Traits<DT>::raw_t;
@@ -229,33 +189,36 @@ __global__ void __launch_bounds__(kT) k_int_cols_quant_vec(const void* in, float
                                                            const uint32_t* ws, float maxq, float zero)
 {
     constexpr int VEC = Traits<DT>::VEC;
+    constexpr int R = 16;                                  // rows per batch: all their loads are issued before anything waits
     const int64_t ipr = C / VEC;
     const int64_t cg = (int64_t)blockIdx.x * kT + threadIdx.x;
     if (cg >= ipr) return;
-    IntScale scale[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; j++) scale[j] = int_scale_inv(int_scale(key_f(ws[cg * VEC + j]), key_f(~ws[C + cg * VEC + j]), maxq));
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
     const int64_t r1 = r0 + rows_per_chunk < outer ? r0 + rows_per_chunk : outer;
-    for (int64_t r = r0; r < r1; r += 4) {                 // four rows per trip: their loads are in flight together
-        uint4 q[4];
+    const uint4* src = reinterpret_cast<const uint4*>(in);
+    uint4 q[R];
 #pragma unroll
-        for (int k = 0; k < 4; k++) q[k] = reinterpret_cast<const uint4*>(in)[(r + k < r1 ? r + k : r1 - 1) * ipr + cg];
+    for (int k = 0; k < R; k++) q[k] = src[(r0 + k < r1 ? r0 + k : r1 - 1) * ipr + cg];
+    // the scales (two dependent L2 round trips and VEC divisions) are worked out while the first batch is in flight: a
+    // workgroup lives for one or two batches, so a set-up in front of the loads left the memory pipe idle a third of the time
+    float scale[VEC];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            float v[VEC];
-            if constexpr (VEC == 4) { v[0] = u2f(q[k].x); v[1] = u2f(q[k].y); v[2] = u2f(q[k].z); v[3] = u2f(q[k].w); }
-            else {
-                const uint32_t d[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+    for (int j = 0; j < VEC; j++) scale[j] = int_scale(key_f(ws[cg * VEC + j]), key_f(~ws[C + cg * VEC + j]), maxq);
 #pragma unroll
-                for (int j = 0; j < 4; j++) { v[2 * j] = raw_to_f32<DT>(d[j] & 0xffffu); v[2 * j + 1] = raw_to_f32<DT>(d[j] >> 16); }
-            }
-            int_q_vec<VEC, true>(v, scale, zero, maxq);
-            if (r + k < r1) {
-                float4* o = reinterpret_cast<float4*>(out) + ((r + k) * ipr + cg) * (VEC / 4);
-                o[0] = make_float4(v[0], v[1], v[2], v[3]);
-                if constexpr (VEC == 8) o[1] = make_float4(v[4], v[5], v[6], v[7]);
-            }
+    for (int k = 0; k < R; k++) {                          // (rows_per_chunk <= R: one batch per thread)
+        float v[VEC];
+        if constexpr (VEC == 4) { v[0] = u2f(q[k].x); v[1] = u2f(q[k].y); v[2] = u2f(q[k].z); v[3] = u2f(q[k].w); }
+        else {
+            const uint32_t d[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) { v[2 * j] = raw_to_f32<DT>(d[j] & 0xffffu); v[2 * j + 1] = raw_to_f32<DT>(d[j] >> 16); }
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; j++) v[j] = int_q(v[j], scale[j], zero, maxq);
+        if (r0 + k < r1) {
+            float4* o = reinterpret_cast<float4*>(out) + ((r0 + k) * ipr + cg) * (VEC / 4);
+            o[0] = make_float4(v[0], v[1], v[2], v[3]);
+            if constexpr (VEC == 8) o[1] = make_float4(v[4], v[5], v[6], v[7]);
         }
     }
 }
@@ -334,12 +297,13 @@ __global__ void __launch_bounds__(kT) k_int_rows_vec(const void* in, float* out,
             __syncthreads();
         }
         if (nan) { mn = u2f(0x7fc00000u); mx = mn; }
-        const IntScale scale = int_scale_inv(int_scale(mn, mx, maxq));
+        const float scale = int_scale(mn, mx, maxq);
         if (live)
             for (int64_t i = lig; i < ipr; i += G) {
                 float v[VEC];
                 load8(base + i, v);
-                int_q_vec<VEC, false>(v, &scale, zero, maxq);
+#pragma unroll
+                for (int j = 0; j < VEC; j++) v[j] = int_q(v[j], scale, zero, maxq);
                 float4* o = reinterpret_cast<float4*>(out) + (base + i) * (VEC / 4);
                 o[0] = make_float4(v[0], v[1], v[2], v[3]);
                 if constexpr (VEC == 8) o[1] = make_float4(v[4], v[5], v[6], v[7]);
@@ -388,15 +352,14 @@ __global__ void __launch_bounds__(kT) k_int_rows_reg(const void* in, float* out,
 #pragma unroll
         for (int i = 0; i < kT / 64; i++) { mn = fminf(mn, s_mn[ph][i]); mx = fmaxf(mx, s_mx[ph][i]); nan |= s_nan[ph][i] != 0; }
         if (nan) { mn = u2f(0x7fc00000u); mx = mn; }
-        const IntScale scale = int_scale_inv(int_scale(mn, mx, maxq));
+        const float scale = int_scale(mn, mx, maxq);
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
             const int64_t i = (int64_t)k * kT + threadIdx.x;
-            float o[VEC];
-#pragma unroll
-            for (int j = 0; j < VEC; j++) o[j] = v[k][j];
-            int_q_vec<VEC, false>(o, &scale, zero, maxq);          // (outside the guard: it holds a wave vote)
             if (i < ipr) {
+                float o[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; j++) o[j] = int_q(v[k][j], scale, zero, maxq);
                 float4* dst = reinterpret_cast<float4*>(out) + (c * ipr + i) * (VEC / 4);
                 dst[0] = make_float4(o[0], o[1], o[2], o[3]);
                 if constexpr (VEC == 8) dst[1] = make_float4(o[4], o[5], o[6], o[7]);
@@ -504,9 +467,16 @@ int run_int(const void* in, float* out, int64_t outer, int64_t C, int64_t inner,
         };
         // min/max: every thread ends with 2*VEC atomics, so give it at least 32 rows; quantize: per-thread scale set-up, 16 rows
         int64_t rpc_mm, rpc_q;
-        const unsigned gy_mm = chunking(32, 1024, &rpc_mm), gy_q = chunking(16, 1024, &rpc_q);   // (8 scale divisions per thread up front: >= 16 rows each)
+        const unsigned gy_mm = chunking(32, 1024, &rpc_mm);
+        rpc_q = 16;                                                    // the quantize launch: one batch of 16 rows per thread
         hipLaunchKernelGGL((k_int_cols_minmax_vec<DT>), dim3((unsigned)gx, gy_mm), dim3(kT), 0, s, in, outer, C, rpc_mm, ws);
-        hipLaunchKernelGGL((k_int_cols_quant_vec<DT>), dim3((unsigned)gx, gy_q), dim3(kT), 0, s, in, out, outer, C, rpc_q, (const uint32_t*)ws, maxq, zero);
+        const int64_t rows_per_launch = rpc_q * 65535;                 // (grid.y limit: more than a million rows go in several launches)
+        for (int64_t row0 = 0; row0 < outer; row0 += rows_per_launch) {
+            const int64_t n = outer - row0 < rows_per_launch ? outer - row0 : rows_per_launch;
+            hipLaunchKernelGGL((k_int_cols_quant_vec<DT>), dim3((unsigned)gx, (unsigned)((n + rpc_q - 1) / rpc_q)), dim3(kT), 0, s,
+                               (const void*)(reinterpret_cast<const char*>(in) + row0 * C * (int64_t)sizeof(typename Traits<DT>::raw_t)), out + row0 * C,
+                               n, C, rpc_q, (const uint32_t*)ws, maxq, zero);
+        }
     } else if (inner == 1) {
         int64_t chunks = (outer + 63) / 64;
         if (chunks > 1024) chunks = 1024;

@@ -25,6 +25,7 @@
 using namespace bfpq;
 
 extern "C" __attribute__((visibility("hidden"))) int bfpq_g_gemm_rt;   // bfpq_gemm.hip
+extern "C" __attribute__((visibility("hidden"))) int bfpq_g_mx8_variant;   // bfpq_mxgemm.hip
 
 #include "bfpq_device.h"
 #include "bfpq_quant_math.h"
@@ -546,6 +547,7 @@ int bfpq_tune(int key, int value)
 {
     if (key == BFPQ_TUNE_MAX_GRID && value >= 1 && value <= 65535) { bfpq_g_max_grid = value; return 0; }
     if (key == BFPQ_TUNE_GEMM_ROW_TILES && (value == 0 || value == 1 || value == 2 || value == 4)) { bfpq_g_gemm_rt = value; return 0; }
+    if (key == BFPQ_TUNE_MX8_VARIANT && value >= -1 && value <= 2) { bfpq_g_mx8_variant = value; return 0; }
     return BFPQ_E_ARG;
 }
 
@@ -704,6 +706,27 @@ int bfpq_quantize_nm(const void* in, void* out_deq, void* out_codes, int8_t* out
     rc = quantize_stage(in, tmp);
     if (rc) return rc;
     return launch_nm_rows(tmp, tmp, out_codes, code_bits, rows, cols, dtype, N, M, M == 8 ? nm4_lut : nullptr, s);
+}
+
+int bfpq_quantize_mx8(const void* in, void* out8, void* out_scale, int64_t rows, int64_t cols, int dtype, int mant_bits, double epsilon,
+                      const uint8_t* exp_win, void* stream)
+{
+    if (dtype < 0 || dtype > 2 || rows < 0 || cols < 0 || mant_bits < 1 || mant_bits > 4) return BFPQ_E_ARG;
+    if (rows * cols == 0) return 0;
+    if (!in || !out8 || !out_scale || !exp_win) return BFPQ_E_ARG;
+    if (dtype == BFPQ_F32 || cols % 64 != 0) return BFPQ_E_UNSUPPORTED;                 // (callers take bfpq_quantize_nm + bfpq_mx8_from_hbfp)
+    if ((reinterpret_cast<uintptr_t>(in) & 15u) || (reinterpret_cast<uintptr_t>(out8) & 7u) || (reinterpret_cast<uintptr_t>(out_scale) & 7u)) return BFPQ_E_UNSUPPORTED;
+    const float eps_dt = h_round((float)epsilon, dtype);
+    FusedArgs a;
+    a.in = in; a.out_deq = nullptr; a.out_codes = out8; a.out_exp = reinterpret_cast<int8_t*>(out_scale);
+    a.n_items = rows * cols / 8;
+    a.exp_win = exp_win; a.nm_lut = nullptr; a.seed = 0; a.eps_dt = eps_dt;
+    a.lpb = 8;
+    a.mant_bits = mant_bits; a.N = 0; a.code_bits = 8;
+    a.force_slow = 0;
+    set_hot16(a, dtype, mant_bits, eps_dt);
+    a.selws = nullptr;
+    return fused_mx8(dtype, a, (hipStream_t)stream);
 }
 
 int bfpq_fake_quantize(const bfpq_plan* p, const void* in, void* out, int64_t rows, int64_t cols, void* stream)

@@ -18,9 +18,9 @@
 // from lane row), bytes 16-31 the second (scale taken from lane row+32) -- with one HBFP block per instruction every lane simply
 // supplies its row's scale.  D: column = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 //
-// Structure: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 = 2x2 instruction tiles each), K step of
+// Structure (default variant): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 = 2x2 instruction tiles each), K step of
 // 128 bytes staged global -> LDS by 16-byte LDS-DMA (global_load_lds_dwordx4), LDS rows of 128 bytes with the 16-byte slot
-// XOR-swizzled by (row & 7) on the source address and on the read (conflict-free ds_read_b128), 32 KB of LDS and ~128 VGPRs so
+// XOR-swizzled by ((row >> 1) & 7) on the source address and on the read (conflict-free ds_read_b128), 32 KB of LDS and ~128 VGPRs so
 // that several workgroups per CU overlap each other's staging.  Workgroup ids are remapped so that the workgroups of one XCD
 // walk the token tiles of the same weight tile (the weight tile is fetched into that XCD's L2 once).
 #include <hip/hip_runtime.h>
@@ -36,7 +36,7 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 128;
+constexpr int BK = 128;                                  // bytes of K per LDS stage: two HBFP blocks
 
 // e4m3 byte of an integer of magnitude m <= 15 (exact): 0, 1 = 0x38, then 0x38 + 4m (2..3), 0x40 + 2m (4..7), 0x48 + m (8..15)
 __device__ __forceinline__ uint32_t e4m3_of_mag(uint32_t m)
@@ -82,35 +82,43 @@ __global__ void __launch_bounds__(256) k_mx8_from_codes(const uint8_t* __restric
 
 __device__ __forceinline__ v8i read_frag(const uint8_t* tile, int row, int c)       // 32 bytes: 16-byte slots c, c+1 of the row
 {
-    const int sw = row & 7;
+    const int sw = (row >> 1) & 7;
     const v4i a0 = *reinterpret_cast<const v4i*>(tile + row * BK + ((c ^ sw) << 4));
     const v4i a1 = *reinterpret_cast<const v4i*>(tile + row * BK + (((c + 1) ^ sw) << 4));
     return v8i{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 }
 
-template <int OP>
-__device__ __forceinline__ void block_mfma(const uint8_t* sA, const uint8_t* sB, int b, int rowA, int rowB, int half, v16f (&acc)[2][2],
-                                           const int (&sa)[2], const int (&sb)[2])
+// one HBFP block (64 of K) of the wave's TM x TN instruction tiles; OP = which byte of the scale registers
+template <int OP, int TM, int TN>
+__device__ __forceinline__ void block_mfma(const uint8_t* sA, const uint8_t* sB, int b, int rowA, int rowB, int half, v16f (&acc)[TM][TN],
+                                           const int (&sa)[TM], const int (&sb)[TN])
 {
     const int c = b * 4 + half * 2;
-    v8i aF[2], bF[2];
+    v8i aF[TM], bF[TN];
 #pragma unroll
-    for (int i = 0; i < 2; i++) { aF[i] = read_frag(sA, rowA + 32 * i, c); bF[i] = read_frag(sB, rowB + 32 * i, c); }
+    for (int i = 0; i < TM; i++) aF[i] = read_frag(sA, rowA + 32 * i, c);
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int j = 0; j < TN; j++) bF[j] = read_frag(sB, rowB + 32 * j, c);
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
             acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aF[i], bF[j], acc[i][j], 0, 0, OP, sa[i], OP, sb[j]);
 }
 
-template <int OUT_DT>
-__global__ void __launch_bounds__(256) k_mx8_gemm(const uint8_t* __restrict__ x8, const uint8_t* __restrict__ xs, const uint8_t* __restrict__ w8,
-                                                  const uint8_t* __restrict__ wsc, const void* __restrict__ bias, void* __restrict__ out,
-                                                  int T, int N, int K, int tiles_t)
+// WM x WN waves, each TM x TN instruction tiles of 32 x 32: output tile BM x BN = (32 WM TM) x (32 WN TN).
+// DBUF: two LDS stages; the next K step's LDS-DMA is issued before the current step's matrix work and waited for after it
+// (one barrier per step).  The block scales are ordinary loads: they are fetched one trip (256 of K) ahead, in front of the
+// DMA of that trip, so that their first use lies behind a wait that has drained the queue anyway.
+template <int OUT_DT, int WM, int WN, int TM, int TN, bool DBUF>
+__global__ void __launch_bounds__(64 * WM * WN) k_mx8_gemm(const uint8_t* __restrict__ x8, const uint8_t* __restrict__ xs, const uint8_t* __restrict__ w8,
+                                                           const uint8_t* __restrict__ wsc, const void* __restrict__ bias, void* __restrict__ out,
+                                                           int T, int N, int K, int tiles_t)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[(BM + BN) * BK];
-    uint8_t* const sA = lds;
-    uint8_t* const sB = lds + BM * BK;
+    constexpr int NW = WM * WN, BM = 32 * WM * TM, BN = 32 * WN * TN, STAGE = (BM + BN) * BK;
+    constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;            // LDS-DMA instructions per wave and stage (8 rows = 1 KB each)
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
+    __shared__ __attribute__((aligned(16))) uint8_t lds[(DBUF ? 2 : 1) * STAGE];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     // workgroups that share an XCD (id % 8) get consecutive tile numbers: token tiles fastest, so they share a weight tile
     const int nwg = gridDim.x, orig = blockIdx.x;
@@ -119,78 +127,150 @@ __global__ void __launch_bounds__(256) k_mx8_gemm(const uint8_t* __restrict__ x8
     const int t0 = (wg % tiles_t) * BM, n0 = (wg / tiles_t) * BN;
     const int nb = K >> 6;                                           // blocks per row = scale bytes per row
 
-    // staging: instruction i of wave w fills LDS rows (4i+w)*8 .. +7 (1 KB, lane-linear); lane l = row l>>3, slot l&7 holds
-    // the row's 16-byte piece slot ^ (row & 7)
-    size_t offA[4], offB[4];
+    // staging: instruction i of wave w fills LDS rows (NW i + w) * 8 .. +7 (1 KB, lane-linear); lane l = row l>>3, slot l&7 holds
+    // the row's 16-byte piece slot ^ ((row >> 1) & 7).  LDS rows are 128 bytes = half of the 64 banks, so the row's parity picks the
+    // half and the swizzle must spread the 8 slots over the row PAIRS of a ds_read_b128 lane group ({0-3,12-15,20-27}, ...):
+    // with (row & 7) rows 12 and 20 of a group met on the same banks (2-way conflict on every fragment read)
+    size_t offA[GA], offB[GB];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int row = (4 * i + w) * 8 + (l >> 3), piece = ((l & 7) ^ (row & 7)) << 4;
-        const int ta = t0 + row < T ? t0 + row : T - 1, na = n0 + row < N ? n0 + row : N - 1;     // rows past the edge repeat the last row
+    for (int i = 0; i < GA; i++) {
+        const int row = (NW * i + w) * 8 + (l >> 3), piece = ((l & 7) ^ ((row >> 1) & 7)) << 4;
+        const int ta = t0 + row < T ? t0 + row : T - 1;                                          // rows past the edge repeat the last row
         offA[i] = (size_t)ta * K + piece;
+    }
+#pragma unroll
+    for (int i = 0; i < GB; i++) {
+        const int row = (NW * i + w) * 8 + (l >> 3), piece = ((l & 7) ^ ((row >> 1) & 7)) << 4;
+        const int na = n0 + row < N ? n0 + row : N - 1;
         offB[i] = (size_t)na * K + piece;
     }
-    const int wr = w >> 1, wc = w & 1, half = l >> 5;
-    const int rowA = wr * 64 + (l & 31), rowB = wc * 64 + (l & 31);
-    const uint32_t* sxp[2];
-    const uint32_t* swp[2];
+    const int wr = w / WN, wc = w % WN, half = l >> 5;
+    const int rowA = wr * (32 * TM) + (l & 31), rowB = wc * (32 * TN) + (l & 31);
+    uint32_t sxo[TM], swo[TN];                                       // dword index of the row's first scale
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int ta = t0 + rowA + 32 * i < T ? t0 + rowA + 32 * i : T - 1, na = n0 + rowB + 32 * i < N ? n0 + rowB + 32 * i : N - 1;
-        sxp[i] = reinterpret_cast<const uint32_t*>(xs + (size_t)ta * nb);
-        swp[i] = reinterpret_cast<const uint32_t*>(wsc + (size_t)na * nb);
-    }
-    v16f acc[2][2];
+    for (int i = 0; i < TM; i++) { const int ta = t0 + rowA + 32 * i < T ? t0 + rowA + 32 * i : T - 1; sxo[i] = (uint32_t)ta * (uint32_t)(nb >> 2); }
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int j = 0; j < TN; j++) { const int na = n0 + rowB + 32 * j < N ? n0 + rowB + 32 * j : N - 1; swo[j] = (uint32_t)na * (uint32_t)(nb >> 2); }
+    const uint32_t* const xs32 = reinterpret_cast<const uint32_t*>(xs);
+    const uint32_t* const ws32 = reinterpret_cast<const uint32_t*>(wsc);
+    v16f acc[TM][TN];
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
-    auto stage = [&](int k0) __attribute__((always_inline)) {
+    auto stage = [&](int k0, int buf) __attribute__((always_inline)) {
+        uint8_t* const sA = lds + buf * STAGE;
+        uint8_t* const sB = sA + BM * BK;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < GA; i++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x8 + offA[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(sA + (4 * i + w) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w8 + offB[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(sB + (4 * i + w) * 1024), 16, 0, 0);
-        }
-    };
-
-    for (int k0 = 0; k0 < K; k0 += 2 * BK) {                         // 4 blocks per trip: one scale dword per operand row
-        int sa[2], sb[2];
+                                             (__attribute__((address_space(3))) void*)(sA + (NW * i + w) * 1024), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 2; i++) { sa[i] = (int)sxp[i][k0 >> 8]; sb[i] = (int)swp[i][k0 >> 8]; }
-        stage(k0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        block_mfma<0>(sA, sB, 0, rowA, rowB, half, acc, sa, sb);
-        block_mfma<1>(sA, sB, 1, rowA, rowB, half, acc, sa, sb);
-        __syncthreads();
-        stage(k0 + BK);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        block_mfma<2>(sA, sB, 0, rowA, rowB, half, acc, sa, sb);
-        block_mfma<3>(sA, sB, 1, rowA, rowB, half, acc, sa, sb);
-        __syncthreads();
+        for (int i = 0; i < GB; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w8 + offB[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(sB + (NW * i + w) * 1024), 16, 0, 0);
+    };
+    auto landed = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); };
+
+    int sa[TM], sb[TN];
+    if constexpr (DBUF) {
+        const uint8_t* const sA0 = lds;
+        const uint8_t* const sB0 = lds + BM * BK;
+        const uint8_t* const sA1 = lds + STAGE;
+        const uint8_t* const sB1 = lds + STAGE + BM * BK;
+#pragma unroll
+        for (int i = 0; i < TM; i++) sa[i] = (int)xs32[sxo[i]];
+#pragma unroll
+        for (int j = 0; j < TN; j++) sb[j] = (int)ws32[swo[j]];
+        stage(0, 0);
+        landed();
+        const int trips = K >> 8;
+        for (int tr = 0; tr < trips; tr++) {
+            const int k0 = tr << 8;
+            const int trn = tr + 1 < trips ? tr + 1 : tr;                 // (last trip: re-reads its own scales, re-stages its own last step)
+            int san[TM], sbn[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) san[i] = (int)xs32[sxo[i] + trn];
+#pragma unroll
+            for (int j = 0; j < TN; j++) sbn[j] = (int)ws32[swo[j] + trn];
+            stage(k0 + BK, 1);
+            block_mfma<0, TM, TN>(sA0, sB0, 0, rowA, rowB, half, acc, sa, sb);
+            block_mfma<1, TM, TN>(sA0, sB0, 1, rowA, rowB, half, acc, sa, sb);
+            landed();
+            stage(trn << 8, 0);
+            block_mfma<2, TM, TN>(sA1, sB1, 0, rowA, rowB, half, acc, sa, sb);
+            block_mfma<3, TM, TN>(sA1, sB1, 1, rowA, rowB, half, acc, sa, sb);
+            landed();
+#pragma unroll
+            for (int i = 0; i < TM; i++) sa[i] = san[i];
+#pragma unroll
+            for (int j = 0; j < TN; j++) sb[j] = sbn[j];
+        }
+    } else {
+        const uint8_t* const sA = lds;
+        const uint8_t* const sB = lds + BM * BK;
+        for (int k0 = 0; k0 < K; k0 += 2 * BK) {                         // 4 blocks per trip: one scale dword per operand row
+#pragma unroll
+            for (int i = 0; i < TM; i++) sa[i] = (int)xs32[sxo[i] + (k0 >> 8)];
+#pragma unroll
+            for (int j = 0; j < TN; j++) sb[j] = (int)ws32[swo[j] + (k0 >> 8)];
+            stage(k0, 0);
+            landed();
+            block_mfma<0, TM, TN>(sA, sB, 0, rowA, rowB, half, acc, sa, sb);
+            block_mfma<1, TM, TN>(sA, sB, 1, rowA, rowB, half, acc, sa, sb);
+            __syncthreads();
+            stage(k0 + BK, 0);
+            landed();
+            block_mfma<2, TM, TN>(sA, sB, 0, rowA, rowB, half, acc, sa, sb);
+            block_mfma<3, TM, TN>(sA, sB, 1, rowA, rowB, half, acc, sa, sb);
+            __syncthreads();
+        }
     }
 
     // epilogue: D column = lane & 31 (n), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (t)
     using raw_t = typename Traits<OUT_DT>::raw_t;
     raw_t* const o = reinterpret_cast<raw_t*>(out);
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int n = n0 + wc * 64 + 32 * j + (l & 31);
+    for (int j = 0; j < TN; j++) {
+        const int n = n0 + wc * (32 * TN) + 32 * j + (l & 31);
         if (n >= N) continue;
         const float bv = bias ? raw_to_f32<OUT_DT>((uint32_t)reinterpret_cast<const raw_t*>(bias)[n]) : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const int t = t0 + wr * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+                const int t = t0 + wr * (32 * TM) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
                 if (t < T) o[(size_t)t * N + n] = (raw_t)f32_to_raw<OUT_DT>(acc[i][j][e] + bv);
             }
     }
+}
+
+// Tile variants (bfpq_tune key BFPQ_TUNE_MX8_VARIANT; measured with tools_dev/ab_mx8.py, all bit-identical):
+//   0: 128 x 128, 4 waves, one LDS stage, ~3 workgroups per CU      -- the default
+//   1: 128 x 128, 4 waves, two stages (next step's DMA under the matrix work), 2 workgroups per CU: +-5 % around variant 0
+//   2: 256 x 256, 8 waves, two stages, 1 workgroup per CU: half the operand traffic per flop; wins (3-6 %) only when there
+//      are enough tiles to fill the 256 CUs several times over, loses up to 50 % otherwise (344 tiles on 256 CUs)
+//   (256 x 128 and 128 x 256 with 8 waves measured 10-25 % slower than variant 0 on every shape and were removed)
+struct MxCfg { int bm, bn; };
+constexpr MxCfg kMxCfg[] = {{128, 128}, {128, 128}, {256, 256}};
+constexpr int kMxVariants = 3;
+
+template <int OUT_DT>
+int launch_mx8(int variant, const uint8_t* a, const uint8_t* as, const uint8_t* b, const uint8_t* bs, const void* bias, void* out,
+               int T, int N, int K, hipStream_t s)
+{
+    const int bm = kMxCfg[variant].bm, bn = kMxCfg[variant].bn;
+    const int tiles_t = (T + bm - 1) / bm, tiles_n = (N + bn - 1) / bn;
+    const dim3 grid((unsigned)(tiles_t * tiles_n));
+    switch (variant) {
+        case 0: hipLaunchKernelGGL((k_mx8_gemm<OUT_DT, 2, 2, 2, 2, false>), grid, dim3(256), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
+        case 1: hipLaunchKernelGGL((k_mx8_gemm<OUT_DT, 2, 2, 2, 2, true>), grid, dim3(256), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
+        default: hipLaunchKernelGGL((k_mx8_gemm<OUT_DT, 2, 4, 4, 2, true>), grid, dim3(512), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
+    }
+    return (int)hipGetLastError();
 }
 
 }  // namespace
@@ -215,9 +295,11 @@ int bfpq_mx8_from_hbfp(const void* codes, const int8_t* exps, void* out8, void* 
 
 int bfpq_hbfp_linear_mx8_ok(int64_t T, int64_t N, int64_t K)
 {
-    return T >= 1 && N >= 1 && K >= 256 && K % 256 == 0 && T * K < ((int64_t)1 << 40) && N * K < ((int64_t)1 << 40) &&
-           ((T + BM - 1) / BM) * ((N + BN - 1) / BN) < ((int64_t)1 << 30);
+    return T >= 1 && N >= 1 && K >= 256 && K % 256 == 0 && T * (K / 256) < ((int64_t)1 << 32) && N * (K / 256) < ((int64_t)1 << 32) &&
+           ((T + 127) / 128) * ((N + 127) / 128) < ((int64_t)1 << 30);
 }
+
+__attribute__((visibility("hidden"))) int bfpq_g_mx8_variant = -1;             // -1 = choose; 0..2 force (bfpq_tune, BFPQ_TUNE_MX8_VARIANT)
 
 int bfpq_hbfp_linear_mx8(const void* x8, const void* xs, const void* w8, const void* ws, const void* bias, void* out,
                          int64_t T, int64_t N, int64_t K, int out_dtype, void* stream)
@@ -228,14 +310,13 @@ int bfpq_hbfp_linear_mx8(const void* x8, const void* xs, const void* w8, const v
     if (!x8 || !xs || !w8 || !ws || !out) return BFPQ_E_ARG;
     if ((reinterpret_cast<uintptr_t>(x8) | reinterpret_cast<uintptr_t>(w8)) & 15u) return BFPQ_E_ARG;
     if ((reinterpret_cast<uintptr_t>(xs) | reinterpret_cast<uintptr_t>(ws)) & 3u) return BFPQ_E_ARG;
-    const int tiles_t = (int)((T + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
-    const dim3 grid((unsigned)(tiles_t * tiles_n));
+    int variant = bfpq_g_mx8_variant;
+    if (variant < 0 || variant >= kMxVariants) variant = ((T + 255) / 256) * ((N + 255) / 256) >= 1024 ? 2 : 0;
     hipStream_t s = (hipStream_t)stream;
     const uint8_t *a = (const uint8_t*)x8, *as = (const uint8_t*)xs, *b = (const uint8_t*)w8, *bs = (const uint8_t*)ws;
-    if (out_dtype == BFPQ_F32) hipLaunchKernelGGL((k_mx8_gemm<BFPQ_F32>), grid, dim3(256), 0, s, a, as, b, bs, bias, out, (int)T, (int)N, (int)K, tiles_t);
-    else if (out_dtype == BFPQ_F16) hipLaunchKernelGGL((k_mx8_gemm<BFPQ_F16>), grid, dim3(256), 0, s, a, as, b, bs, bias, out, (int)T, (int)N, (int)K, tiles_t);
-    else hipLaunchKernelGGL((k_mx8_gemm<BFPQ_BF16>), grid, dim3(256), 0, s, a, as, b, bs, bias, out, (int)T, (int)N, (int)K, tiles_t);
-    return (int)hipGetLastError();
+    if (out_dtype == BFPQ_F32) return launch_mx8<BFPQ_F32>(variant, a, as, b, bs, bias, out, (int)T, (int)N, (int)K, s);
+    if (out_dtype == BFPQ_F16) return launch_mx8<BFPQ_F16>(variant, a, as, b, bs, bias, out, (int)T, (int)N, (int)K, s);
+    return launch_mx8<BFPQ_BF16>(variant, a, as, b, bs, bias, out, (int)T, (int)N, (int)K, s);
 }
 
 }  // extern "C"

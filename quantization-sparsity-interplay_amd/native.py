@@ -18,6 +18,7 @@ _lib = None
 
 F32, F16, BF16 = 0, 1, 2
 DTYPE_CODE = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+BFPQ_E_UNSUPPORTED = -2
 
 EXP_WIN_ENTRIES = 320
 NM4_LUT_ENTRIES = 729
@@ -94,19 +95,20 @@ def load_library():
         L.bfpq_hbfp_linear_tiled_ok.argtypes = [i64, i64]
         L.bfpq_hbfp_linear_decode_tiled.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i32, i32, i32, vp]
         L.bfpq_mx8_from_hbfp.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, vp]
+        L.bfpq_quantize_mx8.argtypes = [vp, vp, vp, i64, i64, i32, i32, dbl, vp, vp]
         L.bfpq_hbfp_linear_mx8_ok.argtypes = [i64, i64, i64]
         L.bfpq_hbfp_linear_mx8.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]
         for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_is_fused", "bfpq_nm_sparsify",
                      "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
                      "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize", "bfpq_hbfp_linear_slices",
                      "bfpq_hbfp_linear_decode", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled",
-                     "bfpq_mx8_from_hbfp", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8"):
+                     "bfpq_mx8_from_hbfp", "bfpq_quantize_mx8", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8"):
             getattr(L, name).restype = i32
         _lib = L
         return _lib
 
 
-EXPORTED_SYMBOLS = ("bfpq_mx8_from_hbfp", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_select_ws_bytes", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24",
+EXPORTED_SYMBOLS = ("bfpq_quantize_mx8", "bfpq_mx8_from_hbfp", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_select_ws_bytes", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_is_fused", "bfpq_nm_sparsify",
                     "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
                     "bfpq_threshold_apply", "bfpq_quantize_threshold")
@@ -663,6 +665,50 @@ def mx8_from_hbfp(codes, exps, cols, mant_bits, code_bits):
     return o8, osc
 
 
+def quantize_mx8(x, mant_bits, epsilon=1e-8):
+    """a 2-D tensor [T, K] -> its HBFP(mant_bits + 1) block-64 image for the block-scaled matrix unit: e4m3 bytes [T, K] + E8M0
+    scales [T, K/64].  16-bit tensors in one pass (bfpq_quantize_mx8); fp32 tensors through int8 codes + mx8_from_hbfp."""
+    require_device_tensor(x)
+    L = load_library()
+    T, K = x.shape
+    dev = x.device
+    with torch.cuda.device(dev):
+        if x.dtype != torch.float32 and K % 64 == 0:
+            x = x.contiguous()
+            x8 = torch.empty((T, K), dtype=torch.uint8, device=dev)
+            xs = torch.empty((T, K // 64), dtype=torch.uint8, device=dev)
+            rc = L.bfpq_quantize_mx8(_ptr(x), _ptr(x8), _ptr(xs), T, K, DTYPE_CODE[x.dtype], int(mant_bits), float(epsilon),
+                                     _ptr(exp_window_dev(x.dtype, dev)), _stream(x))
+            if rc == 0:
+                return x8, xs
+            if rc != BFPQ_E_UNSUPPORTED:
+                check(rc, "bfpq_quantize_mx8")
+        xc = torch.empty((T, K), dtype=torch.int8, device=dev)
+        xe = torch.empty((T, K // 64), dtype=torch.int8, device=dev)
+        quantize_nm(x, 64, mant_bits, epsilon, want_deq=False, code_bits=8, want_exp=True, codes_out=xc, exps_out=xe)
+        return mx8_from_hbfp(xc, xe, K, mant_bits, 8)
+
+
+_last_image = {}          # device -> (key, the tensor itself, image): q/k/v (and gate/up) of a block are called on the same tensor
+SHARE_ACT_IMAGE = True    # False: every call quantizes its activation (single-layer benchmarks that re-use one input tensor)
+
+
+def _shared_image(x2, mant_bits, epsilon):
+    """quantize_mx8 with a one-entry memo per device: the projections that share an input (q/k/v, gate/up) quantize it once.
+    The entry holds the tensor it was made from, so that tensor's memory cannot be handed to another tensor while the entry
+    lives; the key includes the in-place version counter."""
+    key = (x2.data_ptr(), x2._version, tuple(x2.shape), tuple(x2.stride()), x2.dtype, int(mant_bits), float(epsilon),
+           torch.cuda.current_stream(x2.device).cuda_stream)
+    if not SHARE_ACT_IMAGE:
+        return quantize_mx8(x2, mant_bits, epsilon)
+    hit = _last_image.get(x2.device)
+    if hit is not None and hit[0] == key:
+        return hit[2]
+    img = quantize_mx8(x2, mant_bits, epsilon)
+    _last_image[x2.device] = (key, x2, img)
+    return img
+
+
 def hbfp_linear_mx8_ok(T, N, K, w_mant_bits, x_mant_bits, block_size=64):
     return block_size == 64 and 1 <= w_mant_bits <= 4 and 1 <= x_mant_bits <= 4 and bool(load_library().bfpq_hbfp_linear_mx8_ok(T, N, K))
 
@@ -681,10 +727,7 @@ def hbfp_linear_mx8(x, w8, wscale, x_mant_bits, epsilon=1e-8, bias=None, out_dty
     dev = x.device
     out_dtype = out_dtype or x.dtype
     with torch.cuda.device(dev):
-        xc = torch.empty((T, K), dtype=torch.int8, device=dev)
-        xe = torch.empty((T, K // 64), dtype=torch.int8, device=dev)
-        quantize_nm(x.reshape(T, K), 64, x_mant_bits, epsilon, want_deq=False, code_bits=8, want_exp=True, codes_out=xc, exps_out=xe)
-        x8, xs = mx8_from_hbfp(xc, xe, K, x_mant_bits, 8)
+        x8, xs = _shared_image(x.reshape(T, K), x_mant_bits, epsilon)
         out = torch.empty((T, N), dtype=out_dtype, device=dev)
         if bias is not None:
             bias = bias.to(out_dtype).contiguous()

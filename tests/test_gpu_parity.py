@@ -763,6 +763,66 @@ def test_packed_consumer_prefill_mx8(N, K, T, dname):
     assert float(err) < tol and torch.equal(torch.isnan(got.cpu()), nan), (float(err), tol)
     # 8-bit activations do not fit e4m3: the entry point must take the decode-and-library route, not a wrong product
     assert not native.hbfp_linear_mx8_ok(T, N, K, 3, 7)
+    # projections that share an input quantize it once (one-entry memo keyed on the tensor and its version counter)
+    native._last_image.clear()
+    g1 = native.hbfp_linear_mx8(x, w8, wsc, 3, out_dtype=torch.float32)
+    img = native._last_image[x.device][2][0]
+    g2 = native.hbfp_linear_mx8(x, w8, wsc, 3, out_dtype=torch.float32)
+    assert native._last_image[x.device][2][0] is img and torch.equal(torch.nan_to_num(g1), torch.nan_to_num(g2))
+    x.mul_(2)                                                          # in-place update: the memo must miss
+    g3 = native.hbfp_linear_mx8(x, w8, wsc, 3, out_dtype=torch.float32)
+    assert native._last_image[x.device][2][0] is not img
+    assert torch.equal(torch.nan_to_num(g3), torch.nan_to_num(g1 * 2))   # (a power-of-two scale moves every block exponent by one)
+    x.div_(2)
+    # every tile variant walks K in the same order: bit-identical results
+    try:
+        ref = None
+        for v in (0, 1, 2):
+            assert native.load_library().bfpq_tune(2, v) == 0
+            g = native.hbfp_linear_mx8(x, w8, wsc, 3, out_dtype=torch.float32)
+            ref = g if ref is None else ref
+            assert torch.equal(torch.nan_to_num(g), torch.nan_to_num(ref)), v
+    finally:
+        native.load_library().bfpq_tune(2, -1)
+
+
+@pytest.mark.parametrize("dname", ["bf16", "f16", "f32"])
+@pytest.mark.parametrize("xm", [3, 4, 2])
+def test_quantize_mx8_equals_codes_then_image(dname, xm):
+    """the one-pass activation image (bfpq_quantize_mx8: lean arithmetic, e4m3 bytes by table look-up) against the two-step
+    route (int8 codes + exponents, which the oracle pins, then bfpq_mx8_from_hbfp), byte for byte -- ordinary blocks, a zero
+    block, blocks on extreme scales (cold tier), an inf block"""
+    dt = DT[dname]
+    x = synth(300, 1024, dt, 1.0, seed=21)
+    x[0, :64] = 0
+    x[1, 64:128] *= 3e4 if dname == "f16" else 1e30
+    x[2, :64] *= 1e-7 if dname == "f16" else 1e-35
+    x[3, 5] = float("inf")
+    x[4, 64:128] = 0.75                                               # ties at the rounding boundary of every element
+    x = x.to(DEV)
+    x8, xs = native.quantize_mx8(x, xm)
+    xc = torch.empty((300, 1024), dtype=torch.int8, device=DEV)
+    xe = torch.empty((300, 16), dtype=torch.int8, device=DEV)
+    native.quantize_nm(x, 64, xm, 1e-8, want_deq=False, code_bits=8, want_exp=True, codes_out=xc, exps_out=xe)
+    w8, ws = native.mx8_from_hbfp(xc, xe, 1024, xm, 8)
+    assert torch.equal(xs, ws)
+    nanblk = (ws == 255).repeat_interleave(64, dim=1)                  # mantissas of a NaN block are "don't care"
+    assert bool(nanblk.any())
+    a, b = x8.clone(), w8.clone()
+    a[nanblk] = 0; b[nanblk] = 0
+    # a two's-complement int8 code has no -0: compare magnitudes and the signs of the non-zero mantissas
+    assert torch.equal(a & 0x7f, b & 0x7f)
+    nz = (b & 0x7f) != 0
+    assert torch.equal(a[nz], b[nz])
+    # and against the oracle's dequantised values: mantissa * 2^(scale - 127)
+    import numpy as np
+    e4 = np.zeros(256, dtype=np.float64)
+    for m, byte in enumerate([0, 0x38, 0x40, 0x44, 0x48, 0x4a, 0x4c, 0x4e] + [0x50 + i for i in range(8)]):
+        e4[byte] = m; e4[byte | 0x80] = -m
+    val = torch.from_numpy(e4[x8.cpu().numpy()]) * torch.exp2(xs.cpu().double() - 127).repeat_interleave(64, dim=1)
+    want = O.float_to_bfp_blocked(x.cpu(), **cfg(mant_bits=xm, block_size=64, device='cpu'), identifier='in').double()
+    ok = ~nanblk.cpu() & torch.isfinite(want) & (xs.cpu().repeat_interleave(64, dim=1) > 0)
+    assert torch.equal(val[ok], want[ok])
 
 
 def test_dist_paths_with_the_native_engine_on_rccl():
