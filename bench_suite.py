@@ -8,6 +8,7 @@ sys.path.insert(0, ROOT)
 import torch
 import quantization_sparsity_interplay_amd as pkg
 from quantization_sparsity_interplay_amd.bfp import bfp_ops
+from quantization_sparsity_interplay_amd import native
 
 DT = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
@@ -44,6 +45,10 @@ CASES = [
     ("int8 per-row: down_proj bf16 weights (fp32 out)", 4096, 11008, "bf16", 6, dict(sparsity_num_format='int', mant_bits=8)),
     ("int8 per-column: activation [4096,4096] bf16 (fp32 out)", 4096, 4096, "bf16", 6, dict(sparsity_num_format='int', mant_bits=8, _ident='in')),
     ("cfg3 tie-heavy input (already HBFP4) bf16 2:4 q", 4096, 11008, "bf16", 4, dict(w_sparsity=True, first='q', _prequant=True)),
+    # packed outputs (north_star "packed int4 stores"): 2 B read + 0.5 B codes + 1/64 B exponents; the matrix unit's image: 2 + 1 + 1/64
+    ("cfg3 down_proj bf16 2:4 s, PACKED output (4-bit codes + int8 exponents)", 4096, 11008, "bf16", 2.516, dict(w_sparsity=True, _packed=4)),
+    ("cfg2 q_proj bf16 dense, PACKED output (4-bit codes + int8 exponents)", 4096, 4096, "bf16", 2.516, dict(_packed=4)),
+    ("activation [2048,11008] bf16 -> e4m3 + E8M0 image (operand of the block-scaled matrix unit)", 2048, 11008, "bf16", 3.016, dict(_packed=8)),
 ]
 
 
@@ -117,6 +122,7 @@ def main():
         kw = dict(kw)
         ident = kw.pop("_ident", "w")
         prequant = kw.pop("_prequant", False)
+        packed = kw.pop("_packed", 0)
         c = cfg(**kw)
         dt = DT[dname]
         numel = rows * cols
@@ -128,7 +134,13 @@ def main():
 
         def run():
             for i in range(L):
-                bfp_ops.float_to_bfp_blocked(ins[i % R], **c, identifier=ident)
+                if packed == 4:
+                    sp = c['w_sparsity']
+                    bfp_ops.float_to_bfp_packed(ins[i % R], c['mant_bits'], c['block_size'], c['epsilon'], c['N'] if sp else 0, c['M'] if sp else 0, c['first'], 4)
+                elif packed == 8:
+                    native.quantize_mx8(ins[i % R], c["mant_bits"], c["epsilon"])
+                else:
+                    bfp_ops.float_to_bfp_blocked(ins[i % R], **c, identifier=ident)
         run()
         torch.cuda.synchronize()
         mode = "hipGraph"

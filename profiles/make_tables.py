@@ -26,4 +26,21 @@ swap_table(os.path.join(ROOT, "profiles", f"{tag}_linear.md"), "| layer |",
            [f"| {r['layer']} | {r['tokens']} | {r['in_features']} x {r['out_features']} | {r['f_linear_us']:.1f} | {r['bfplinear_us']:.1f} | "
             f"{r['bfplinear_cached_us']:.1f} | {r['weight_quant_us']:.1f} | {r['act_quant_us']:.1f} | "
             + (f"{r['packed_decode_us']:.1f}" if r.get('packed_decode_us') else "-") + " |" for r in lin])
+pf = os.path.join(ROOT, "profiles", f"{tag}_prefill.json")
+if os.path.exists(pf):
+    rows = json.load(open(pf))
+    swap_table(os.path.join(ROOT, "profiles", f"{tag}_prefill.md"), "| layer |",
+               [f"| {r['layer']} | {r['tokens']} | {r['in_features']} x {r['out_features']} | {r['f_linear_us']:.1f} ({r['f_linear_tflops']:.0f}) | "
+                f"{r['bfplinear_cached_us']:.1f} | **{r['packed_prefill_us']:.1f}** | {r['act_image_us']:.1f} | {r['mx8_gemm_us']:.1f} ({r['mx8_gemm_tflops']:.0f}) | "
+                f"{r['packed_prefill_us'] / r['f_linear_us']:.2f} |" for r in rows])
+mf = os.path.join(ROOT, "profiles", f"{tag}_model.json")
+if os.path.exists(mf):
+    rows = json.load(open(mf))
+    modes, toks = [], []
+    for r in rows:
+        if r['mode'] not in modes: modes.append(r['mode'])
+        if r['tokens'] not in toks: toks.append(r['tokens'])
+    get = {(r['mode'], r['tokens']): r['us_per_forward'] for r in rows}
+    swap_table(os.path.join(ROOT, "profiles", f"{tag}_model.md"), "| linear layers |",
+               [f"| {m} | " + " | ".join(f"{get[(m, t)]:.0f}" for t in toks) + " |" for m in modes])
 print("tables refreshed")

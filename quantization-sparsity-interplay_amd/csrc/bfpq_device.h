@@ -475,13 +475,19 @@ inline bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 // workgroups for `work_threads` grid-stride work items: at most kMaxGrid, and balanced -- every
 // workgroup gets the same number of sweeps (22016 blocks of work -> 18 sweeps x 1224 workgroups, not
 // 1280 workgroups of which 256 do one sweep more)
-inline int grid_for(int64_t work_threads)
+inline int grid_for_cap(int64_t work_threads, int64_t cap)
 {
     int64_t g = (work_threads + kThreads - 1) / kThreads;
     if (g < 1) g = 1;
-    if (g <= kMaxGrid) return (int)g;
-    const int64_t sweeps = (g + kMaxGrid - 1) / kMaxGrid;
+    if (g <= cap) return (int)g;
+    const int64_t sweeps = (g + cap - 1) / cap;
     return (int)((g + sweeps - 1) / sweeps);
 }
+inline int grid_for(int64_t work_threads) { return grid_for_cap(work_threads, kMaxGrid); }
+// The packed-output instantiations write a quarter (4-bit codes) or half (e4m3 image) of the bytes they read: HBM is not the
+// limit (3.9 TB/s of traffic at the drop-in grid), the number of loads in flight is.  They fit 64 VGPRs, so the cap is raised to
+// fill all 8 wave slots per SIMD (interleaved sweep on [4096,11008] bf16 2:4 packed, tools_dev/ab_grid.py with PACKED=1:
+// 1024 workgroups 29.0 us, 1536 27.8, 2048 26.6, 2752 26.2, 4096 26.6).
+inline int grid_for_packed(int64_t work_threads) { return grid_for_cap(work_threads, (int64_t)kMaxGrid * 43 / 16); }
 
 }  // namespace bfpq_dev

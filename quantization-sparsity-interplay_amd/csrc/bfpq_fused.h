@@ -803,7 +803,7 @@ int launch_fused_l(const FusedArgs& a, hipStream_t s)
     if constexpr (!STOCH && Traits<DT>::VEC == 8 && NM != 2 && NM != 8) {
         // packed 4-bit codes + exponents only, block = 8 lane items: the lean packed instantiation
         if (!a.out_deq && a.out_codes && a.code_bits == 4 && a.out_exp && a.lpb == 8 && (reinterpret_cast<uintptr_t>(a.out_exp) & 7u) == 0) {
-            const dim3 grid(grid_for(a.n_items)), block(kThreads);
+            const dim3 grid(grid_for_packed(a.n_items)), block(kThreads);
             hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, false, 8, false, false, 4>), grid, block, 0, s, a);
             return (int)hipGetLastError();
         }
@@ -823,7 +823,7 @@ template <int DT>
 int launch_fused_mx8(const FusedArgs& a, hipStream_t s)
 {
     if constexpr (Traits<DT>::VEC == 8) {
-        const dim3 grid(grid_for(a.n_items)), block(kThreads);
+        const dim3 grid(grid_for_packed(a.n_items)), block(kThreads);
         hipLaunchKernelGGL((k_fused_flat<DT, 0, true, false, 8, false, false, 8>), grid, block, 0, s, a);
         return (int)hipGetLastError();
     } else return BFPQ_E_UNSUPPORTED;

@@ -36,6 +36,8 @@ typedef int v8i __attribute__((ext_vector_type(8)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
 
+template <int V> struct template_int { static constexpr int value = V; };
+
 constexpr int BK = 128;                                  // bytes of K per LDS stage: two HBFP blocks
 
 // e4m3 byte of an integer of magnitude m <= 15 (exact): 0, 1 = 0x38, then 0x38 + 4m (2..3), 0x40 + 2m (4..7), 0x48 + m (8..15)
@@ -248,15 +250,174 @@ __global__ void __launch_bounds__(64 * WM * WN) k_mx8_gemm(const uint8_t* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The pipelined form.  The counters of the kernel above say it is bound by the rate at which operand bytes reach the CU
+// (both 128 x 128 structures settle at ~27 B/clk/CU = ~14 TB/s over the chip, whatever their overlap), and that the 256 x 256
+// form, which needs half the bytes per flop, is bound by the LATENCY of a two-stage hand-over instead.  So: large tiles AND a
+// deep ring.  One LDS stage = ONE HBFP block (64 bytes of K) of every tile row, four stages in the ring, the DMA of step s+3
+// issued before the matrix work of step s; waits are COUNTED (vmcnt leaves the two youngest stages in flight) and the barrier is
+// the raw s_barrier -- __syncthreads() would drain the DMA queue.  Nothing but LDS-DMA touches global memory in the loop (the
+// block scales travel as one dword per tile row and trip of four blocks into their own little LDS ring), so every wait in it is
+// one written here; all LDS is one array.
+//   LDS rows are 64 bytes = 4 slots of 16; slot' = slot ^ ((row >> 2) & 3) on the DMA source and on the read spreads the 16 rows of
+//   a ds_read_b128 lane group over all 64 banks.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ v8i read_frag64(const uint8_t* tile, int row, int half)  // 32 bytes: slots 2 half, 2 half + 1 of a 64-byte row
+{
+    const int sw = (row >> 2) & 3;
+    const v4i a0 = *reinterpret_cast<const v4i*>(tile + row * 64 + (((2 * half) ^ sw) << 4));
+    const v4i a1 = *reinterpret_cast<const v4i*>(tile + row * 64 + (((2 * half + 1) ^ sw) << 4));
+    return v8i{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int OUT_DT, int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(64 * WM * WN) k_mx8_gemm_ring(const uint8_t* __restrict__ x8, const uint8_t* __restrict__ xs, const uint8_t* __restrict__ w8,
+                                                                const uint8_t* __restrict__ wsc, const void* __restrict__ bias, void* __restrict__ out,
+                                                                int T, int N, int K, int tiles_t)
+{
+    constexpr int NW = WM * WN, NT = 64 * NW, BM = 32 * WM * TM, BN = 32 * WN * TN;
+    constexpr int STAGE = (BM + BN) * 64, NS = 4;
+    constexpr int GA = BM / 16 / NW, GB = BN / 16 / NW, G = GA + GB;           // DMA pieces (16 rows x 64 B = 1 KB) per wave and stage
+    static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile rows must split evenly over the waves");
+    static_assert(NT >= BM + BN, "one thread per tile row carries the row's scales");
+    __shared__ __attribute__((aligned(16))) uint8_t lds[NS * STAGE + 2 * NT * 4];
+    uint8_t* const sscale = lds + NS * STAGE;                                  // [2][NT] dwords: scales of the 4 blocks of a trip, per tile row
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int t0 = (wg % tiles_t) * BM, n0 = (wg / tiles_t) * BN;
+    const int nb = K >> 6, S = nb, trips = nb >> 2;
+
+    size_t offA[GA], offB[GB];
+#pragma unroll
+    for (int i = 0; i < GA; i++) {
+        const int row = (NW * i + w) * 16 + (l >> 2), piece = ((l & 3) ^ ((row >> 2) & 3)) << 4;
+        const int ta = t0 + row < T ? t0 + row : T - 1;
+        offA[i] = (size_t)ta * K + piece;
+    }
+#pragma unroll
+    for (int i = 0; i < GB; i++) {
+        const int row = (NW * i + w) * 16 + (l >> 2), piece = ((l & 3) ^ ((row >> 2) & 3)) << 4;
+        const int na = n0 + row < N ? n0 + row : N - 1;
+        offB[i] = (size_t)na * K + piece;
+    }
+    // this thread's tile row for the scale DMA: rows 0 .. BM-1 = tokens, BM .. BM+BN-1 = output features (threads past that repeat the last)
+    const uint32_t* srow;
+    {
+        const int tr = (int)threadIdx.x < BM + BN ? (int)threadIdx.x : BM + BN - 1;
+        if (tr < BM) { const int ta = t0 + tr < T ? t0 + tr : T - 1; srow = reinterpret_cast<const uint32_t*>(xs) + (size_t)ta * (nb >> 2); }
+        else { const int na = n0 + tr - BM < N ? n0 + tr - BM : N - 1; srow = reinterpret_cast<const uint32_t*>(wsc) + (size_t)na * (nb >> 2); }
+    }
+    const int wr = w / WN, wc = w % WN, half = l >> 5;
+    const int rowA = wr * (32 * TM) + (l & 31), rowB = wc * (32 * TN) + (l & 31);
+    v16f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+    auto stage = [&](int s, int buf) __attribute__((always_inline)) {           // block s of K -> ring slot buf
+        uint8_t* const sA = lds + buf * STAGE;
+        uint8_t* const sB = sA + BM * 64;
+        const int k0 = s << 6;
+#pragma unroll
+        for (int i = 0; i < GA; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x8 + offA[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(sA + (NW * i + w) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < GB; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w8 + offB[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(sB + (NW * i + w) * 1024), 16, 0, 0);
+    };
+    auto stage_scales = [&](int trip) __attribute__((always_inline)) {          // one dword per tile row -> sscale[trip & 1][thread]
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srow + trip),
+                                         (__attribute__((address_space(3))) void*)(sscale + (trip & 1) * NT * 4 + w * 256), 4, 0, 0);
+    };
+    auto hand_over = [&](auto n_tag) __attribute__((always_inline)) {           // counted wait, then the raw barrier
+        wait_vm<decltype(n_tag)::value>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    int sa[TM], sb[TN];
+    auto mm = [&](auto op_tag, int buf) __attribute__((always_inline)) {
+        constexpr int OP = decltype(op_tag)::value;
+        const uint8_t* const sA = lds + buf * STAGE;
+        const uint8_t* const sB = sA + BM * 64;
+        v8i aF[TM], bF[TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) aF[i] = read_frag64(sA, rowA + 32 * i, half);
+#pragma unroll
+        for (int j = 0; j < TN; j++) bF[j] = read_frag64(sB, rowB + 32 * j, half);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aF[i], bF[j], acc[i][j], 0, 0, OP, sa[i], OP, sb[j]);
+    };
+    template_int<0> I0; template_int<1> I1; template_int<2> I2; template_int<3> I3;
+
+    // prologue: scales of trip 0 and blocks 0, 1, 2 (S >= 4 since K % 256 == 0), drained once
+    stage_scales(0);
+    stage(0, 0); stage(1, 1); stage(2, 2);
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    for (int tr = 0; tr < trips; tr++) {
+        const int s = tr << 2;
+        const int trn = tr + 1 < trips ? tr + 1 : tr;
+        const uint32_t* const sc = reinterpret_cast<const uint32_t*>(sscale + (tr & 1) * NT * 4);
+#pragma unroll
+        for (int i = 0; i < TM; i++) sa[i] = (int)sc[rowA + 32 * i];
+#pragma unroll
+        for (int j = 0; j < TN; j++) sb[j] = (int)sc[BM + rowB + 32 * j];
+        // queue (issue order) at each hand-over: ... [s+1][s+2][scales][s+3] | [s+2][scales][s+3][s+4] | [s+3][s+4][s+5] | [s+4][s+5][s+6]
+        stage_scales(trn);
+        stage(s + 3 < S ? s + 3 : S - 1, 3);
+        mm(I0, 0);
+        hand_over(template_int<2 * G + 1>{});                                   // block s+1 landed
+        stage(s + 4 < S ? s + 4 : S - 1, 0);
+        mm(I1, 1);
+        hand_over(template_int<2 * G + 1>{});                                   // block s+2 landed (the scale dword sits behind it)
+        stage(s + 5 < S ? s + 5 : S - 1, 1);
+        mm(I2, 2);
+        hand_over(template_int<2 * G>{});                                       // block s+3 and the next trip's scales landed
+        stage(s + 6 < S ? s + 6 : S - 1, 2);
+        mm(I3, 3);
+        hand_over(template_int<2 * G>{});                                       // block s+4 landed
+    }
+    wait_vm<0>();                                                               // (the clamped re-stages of the tail)
+
+    using raw_t = typename Traits<OUT_DT>::raw_t;
+    raw_t* const o = reinterpret_cast<raw_t*>(out);
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = n0 + wc * (32 * TN) + 32 * j + (l & 31);
+        if (n >= N) continue;
+        const float bv = bias ? raw_to_f32<OUT_DT>((uint32_t)reinterpret_cast<const raw_t*>(bias)[n]) : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int t = t0 + wr * (32 * TM) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (t < T) o[(size_t)t * N + n] = (raw_t)f32_to_raw<OUT_DT>(acc[i][j][e] + bv);
+            }
+    }
+}
+
 // Tile variants (bfpq_tune key BFPQ_TUNE_MX8_VARIANT; measured with tools_dev/ab_mx8.py, all bit-identical):
 //   0: 128 x 128, 4 waves, one LDS stage, ~3 workgroups per CU      -- the default
 //   1: 128 x 128, 4 waves, two stages (next step's DMA under the matrix work), 2 workgroups per CU: +-5 % around variant 0
 //   2: 256 x 256, 8 waves, two stages, 1 workgroup per CU: half the operand traffic per flop; wins (3-6 %) only when there
 //      are enough tiles to fill the 256 CUs several times over, loses up to 50 % otherwise (344 tiles on 256 CUs)
-//   (256 x 128 and 128 x 256 with 8 waves measured 10-25 % slower than variant 0 on every shape and were removed)
+//   (256 x 128 and 128 x 256 with 8 waves measured 10-25 % slower than variant 0 on every shape and were removed; so was a form
+//    with the weight fragments loaded straight into registers, 32 rows x 64 B per load instruction: 1.5x slower)
 struct MxCfg { int bm, bn; };
-constexpr MxCfg kMxCfg[] = {{128, 128}, {128, 128}, {256, 256}};
-constexpr int kMxVariants = 3;
+constexpr MxCfg kMxCfg[] = {{128, 128}, {128, 128}, {256, 256}, {256, 256}, {256, 128}};
+constexpr int kMxVariants = 5;
 
 template <int OUT_DT>
 int launch_mx8(int variant, const uint8_t* a, const uint8_t* as, const uint8_t* b, const uint8_t* bs, const void* bias, void* out,
@@ -268,7 +429,9 @@ int launch_mx8(int variant, const uint8_t* a, const uint8_t* as, const uint8_t* 
     switch (variant) {
         case 0: hipLaunchKernelGGL((k_mx8_gemm<OUT_DT, 2, 2, 2, 2, false>), grid, dim3(256), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
         case 1: hipLaunchKernelGGL((k_mx8_gemm<OUT_DT, 2, 2, 2, 2, true>), grid, dim3(256), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
-        default: hipLaunchKernelGGL((k_mx8_gemm<OUT_DT, 2, 4, 4, 2, true>), grid, dim3(512), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
+        case 2: hipLaunchKernelGGL((k_mx8_gemm<OUT_DT, 2, 4, 4, 2, true>), grid, dim3(512), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
+        case 3: hipLaunchKernelGGL((k_mx8_gemm_ring<OUT_DT, 2, 4, 4, 2>), grid, dim3(512), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
+        default: hipLaunchKernelGGL((k_mx8_gemm_ring<OUT_DT, 4, 2, 2, 2>), grid, dim3(512), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
     }
     return (int)hipGetLastError();
 }

@@ -98,6 +98,37 @@ int main()
                (long long)zeros, (long long)zref, (long long)diff_outside, ok ? "ok" : "MISMATCH");
         fails += !ok;
     }
+    // 3b. prefill consumer: out[T, N] = Q(x) Q(w)^T on the block-scaled matrix instruction, against the double-precision product of
+    //     the oracle's two fake-quantised tensors (w = the first 256 rows of the test data: 2:4 -> HBFP4; x = 200 other rows: dense HBFP4)
+    {
+        const int64_t T = 200, N = 256, K = cols;
+        const uint16_t* hx = h_in.data() + 300 * cols;
+        std::vector<uint16_t> wq(N * K), xq(T * K);
+        if (oracle_float_to_bfp_blocked(h_in.data(), wq.data(), N, K, BFPQ_BF16, 1, 64, 3, 1e-8, 1, 2, 4, 0.5, 1)) return 6;
+        if (oracle_float_to_bfp_blocked(hx, xq.data(), T, K, BFPQ_BF16, 1, 64, 3, 1e-8, 0, 0, 0, 0.5, 1)) return 6;
+        uint8_t *d_w8, *d_ws, *d_x8, *d_xs; float* d_o;
+        HIP(hipMalloc(&d_w8, N * K)); HIP(hipMalloc(&d_ws, N * K / 64)); HIP(hipMalloc(&d_x8, T * K)); HIP(hipMalloc(&d_xs, T * K / 64)); HIP(hipMalloc(&d_o, T * N * 4));
+        RC(bfpq_quantize_nm(d_in, nullptr, d_codes, d_exp, N, K, BFPQ_BF16, 64, 3, 1e-8, 2, 4, 1, 4, 0, d_win, d_lut, nullptr, s));     // the packed weight
+        RC(bfpq_mx8_from_hbfp(d_codes, d_exp, d_w8, d_ws, N, K, 4, 3, s));                                                          // its image, once
+        RC(bfpq_quantize_mx8((const uint16_t*)d_in + 300 * cols, d_x8, d_xs, T, K, BFPQ_BF16, 3, 1e-8, d_win, s));                 // the activation's image, one pass
+        RC(bfpq_hbfp_linear_mx8(d_x8, d_xs, d_w8, d_ws, nullptr, d_o, T, N, K, BFPQ_F32, s));
+        HIP(hipStreamSynchronize(s));
+        std::vector<float> o(T * N);
+        HIP(hipMemcpy(o.data(), d_o, T * N * 4, hipMemcpyDeviceToHost));
+        auto f = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float v; memcpy(&v, &u, 4); return (double)v; };
+        double worst = 0, big = 0;
+        for (int64_t t = 0; t < T; t++)
+            for (int64_t j = 0; j < N; j++) {
+                double acc = 0;
+                for (int64_t k = 0; k < K; k++) acc += f(xq[t * K + k]) * f(wq[j * K + k]);
+                const double d = acc - (double)o[t * N + j];
+                if ((d < 0 ? -d : d) > worst) worst = d < 0 ? -d : d;
+                if ((acc < 0 ? -acc : acc) > big) big = acc < 0 ? -acc : acc;
+            }
+        const bool ok = worst <= 2e-6 * big;
+        printf("prefill from the packed weight (block-scaled matrix instruction) : max error %.3g of %.3g : %s\n", worst, big, ok ? "ok" : "MISMATCH");
+        fails += !ok;
+    }
     // 4. argument errors come back as codes, nothing is launched
     fails += bfpq_quantize_nm(nullptr, d_out, nullptr, nullptr, rows, cols, BFPQ_BF16, 64, 3, 1e-8, 2, 4, 1, 0, 0, d_win, d_lut, nullptr, s) != BFPQ_E_ARG;
     fails += bfpq_quantize_nm(d_in, d_out, nullptr, nullptr, rows, cols, 7, 64, 3, 1e-8, 2, 4, 1, 0, 0, d_win, d_lut, nullptr, s) != BFPQ_E_ARG;

@@ -43,6 +43,20 @@ def test_argument_validation_without_gpu():
     assert L.bfpq_hbfp_linear_decode_tiled(one, one, one, one, one, 65, 4096, 11008, native.BF16, 3, 7, n) == -1     # more than 64 tokens
     assert L.bfpq_hbfp_linear_decode_tiled(one, one, one, one, one, 1, 4096, 11008, native.BF16, 4, 7, n) == -1      # weight mantissa > 3 bits
     assert L.bfpq_hbfp_linear_decode_tiled(one, one, one, one, one, 1, 4096, 1000, native.BF16, 3, 7, n) == -2       # shape the tiled layout does not take
+    # prefill consumer (block-scaled matrix instruction) and its image builders
+    assert L.bfpq_hbfp_linear_mx8_ok(2048, 11008, 4096) == 1 and L.bfpq_hbfp_linear_mx8_ok(2048, 11008, 4160) == 0 and L.bfpq_hbfp_linear_mx8_ok(0, 8, 256) == 0
+    assert L.bfpq_hbfp_linear_mx8(one, one, one, one, n, one, 8, 8, 200, native.BF16, n) == -2                        # K % 256 != 0
+    assert L.bfpq_hbfp_linear_mx8(one, one, one, one, n, one, 8, 8, 256, 7, n) == -1                                  # bad output dtype
+    assert L.bfpq_hbfp_linear_mx8(n, one, one, one, n, one, 8, 8, 256, native.BF16, n) == -1                          # null operand
+    assert L.bfpq_hbfp_linear_mx8(ctypes.c_void_p(8), one, one, one, n, one, 8, 8, 256, native.BF16, n) == -1         # image not 16-byte aligned
+    assert L.bfpq_hbfp_linear_mx8(one, one, one, one, n, one, 0, 8, 256, native.BF16, n) == 0                         # no tokens: ok, no launch
+    assert L.bfpq_mx8_from_hbfp(one, one, one, one, 4, 64, 4, 4, n) == -1                                             # 4-bit codes hold <= 3 mantissa bits
+    assert L.bfpq_mx8_from_hbfp(one, one, one, one, 4, 64, 8, 5, n) == -1                                             # 5 mantissa bits do not fit e4m3
+    assert L.bfpq_mx8_from_hbfp(one, one, one, one, 4, 100, 8, 3, n) == -1                                            # cols % 64 != 0
+    assert L.bfpq_quantize_mx8(one, one, one, 4, 64, native.F32, 3, 1e-8, one, n) == -2                               # fp32: through the codes
+    assert L.bfpq_quantize_mx8(one, one, one, 4, 64, native.BF16, 5, 1e-8, one, n) == -1
+    assert L.bfpq_quantize_mx8(one, one, one, 0, 64, native.BF16, 3, 1e-8, one, n) == 0
+    assert L.bfpq_tune(2, 3) == -1 and L.bfpq_tune(2, 2) == 0 and L.bfpq_tune(2, -1) == 0
     assert L.bfpq_hbfp_linear_decode(one, one, one, one, one, one, 17, 4096, 11008, native.BF16, 3, 7, n) == -1      # row-major layout: <= 16 tokens
     assert L.bfpq_nm8_lut_host(0, one) == -1 and L.bfpq_nm8_lut_host(4, n) == -1
     assert L.bfpq_tune(1, 3) == -1 and L.bfpq_tune(1, 2) == 0 and L.bfpq_tune(1, 0) == 0
