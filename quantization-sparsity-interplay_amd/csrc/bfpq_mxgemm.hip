@@ -272,23 +272,28 @@ __device__ __forceinline__ v8i read_frag64(const uint8_t* tile, int row, int hal
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+template <int WM, int WN, int TM, int TN> struct RingCfg {
+    static constexpr int NW = WM * WN, NT = 64 * NW, BM = 32 * WM * TM, BN = 32 * WN * TN, STAGE = (BM + BN) * 64, NS = 4;
+    static constexpr int LDS_BYTES = NS * STAGE + 2 * NT * 4;
+};
+
+// one output tile: `orig` of `nwg` workgroups of this tile shape (ids remapped per XCD), columns starting at n_base
 template <int OUT_DT, int WM, int WN, int TM, int TN>
-__global__ void __launch_bounds__(64 * WM * WN) k_mx8_gemm_ring(const uint8_t* __restrict__ x8, const uint8_t* __restrict__ xs, const uint8_t* __restrict__ w8,
-                                                                const uint8_t* __restrict__ wsc, const void* __restrict__ bias, void* __restrict__ out,
-                                                                int T, int N, int K, int tiles_t)
+__device__ __forceinline__ void ring_tile(uint8_t* lds, int orig, int nwg, int n_base,
+                                          const uint8_t* __restrict__ x8, const uint8_t* __restrict__ xs, const uint8_t* __restrict__ w8,
+                                          const uint8_t* __restrict__ wsc, const void* __restrict__ bias, void* __restrict__ out,
+                                          int T, int N, int K, int tiles_t)
 {
-    constexpr int NW = WM * WN, NT = 64 * NW, BM = 32 * WM * TM, BN = 32 * WN * TN;
-    constexpr int STAGE = (BM + BN) * 64, NS = 4;
+    using C = RingCfg<WM, WN, TM, TN>;
+    constexpr int NW = C::NW, NT = C::NT, BM = C::BM, BN = C::BN, STAGE = C::STAGE, NS = C::NS;
     constexpr int GA = BM / 16 / NW, GB = BN / 16 / NW, G = GA + GB;           // DMA pieces (16 rows x 64 B = 1 KB) per wave and stage
     static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile rows must split evenly over the waves");
     static_assert(NT >= BM + BN, "one thread per tile row carries the row's scales");
-    __shared__ __attribute__((aligned(16))) uint8_t lds[NS * STAGE + 2 * NT * 4];
     uint8_t* const sscale = lds + NS * STAGE;                                  // [2][NT] dwords: scales of the 4 blocks of a trip, per tile row
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int nwg = gridDim.x, orig = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    const int t0 = (wg % tiles_t) * BM, n0 = (wg / tiles_t) * BN;
+    const int t0 = (wg % tiles_t) * BM, n0 = n_base + (wg / tiles_t) * BN;
     const int nb = K >> 6, S = nb, trips = nb >> 2;
 
     size_t offA[GA], offB[GB];
@@ -408,16 +413,44 @@ __global__ void __launch_bounds__(64 * WM * WN) k_mx8_gemm_ring(const uint8_t* _
     }
 }
 
-// Tile variants (bfpq_tune key BFPQ_TUNE_MX8_VARIANT; measured with tools_dev/ab_mx8.py, all bit-identical):
-//   0: 128 x 128, 4 waves, one LDS stage, ~3 workgroups per CU      -- the default
-//   1: 128 x 128, 4 waves, two stages (next step's DMA under the matrix work), 2 workgroups per CU: +-5 % around variant 0
-//   2: 256 x 256, 8 waves, two stages, 1 workgroup per CU: half the operand traffic per flop; wins (3-6 %) only when there
-//      are enough tiles to fill the 256 CUs several times over, loses up to 50 % otherwise (344 tiles on 256 CUs)
-//   (256 x 128 and 128 x 256 with 8 waves measured 10-25 % slower than variant 0 on every shape and were removed; so was a form
-//    with the weight fragments loaded straight into registers, 32 rows x 64 B per load instruction: 1.5x slower)
+template <int OUT_DT, int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(64 * WM * WN) k_mx8_gemm_ring(const uint8_t* __restrict__ x8, const uint8_t* __restrict__ xs, const uint8_t* __restrict__ w8,
+                                                                const uint8_t* __restrict__ wsc, const void* __restrict__ bias, void* __restrict__ out,
+                                                                int T, int N, int K, int tiles_t)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[RingCfg<WM, WN, TM, TN>::LDS_BYTES];
+    ring_tile<OUT_DT, WM, WN, TM, TN>(lds, (int)blockIdx.x, (int)gridDim.x, 0, x8, xs, w8, wsc, bias, out, T, N, K, tiles_t);
+}
+
+// Two tile shapes in one launch.  256 x 256 tiles need half the operand bytes per flop, but N / 256 x T / 256 of them rarely fill
+// the 256 CUs a whole number of times (2048 tokens x 11008 features: 344 tiles = one full round and a third of a second one).  So
+// the first n_big workgroups (whole rounds of the chip) take 256 x 256 tiles of the first columns, the remaining columns go in
+// 256 x 128 tiles, which are dispatched last and fill the CUs as the big tiles retire.
+template <int OUT_DT>
+__global__ void __launch_bounds__(512) k_mx8_gemm_ring_mixed(const uint8_t* __restrict__ x8, const uint8_t* __restrict__ xs, const uint8_t* __restrict__ w8,
+                                                             const uint8_t* __restrict__ wsc, const void* __restrict__ bias, void* __restrict__ out,
+                                                             int T, int N, int K, int tiles_t, int n_big, int n_base_small)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[RingCfg<2, 4, 4, 2>::LDS_BYTES];
+    if ((int)blockIdx.x < n_big)
+        ring_tile<OUT_DT, 2, 4, 4, 2>(lds, (int)blockIdx.x, n_big, 0, x8, xs, w8, wsc, bias, out, T, N, K, tiles_t);
+    else
+        ring_tile<OUT_DT, 4, 2, 2, 2>(lds, (int)blockIdx.x - n_big, (int)gridDim.x - n_big, n_base_small, x8, xs, w8, wsc, bias, out, T, N, K, tiles_t);
+}
+
+// Tile variants (bfpq_tune key BFPQ_TUNE_MX8_VARIANT; measured with tools_dev/ab_mx8.py, interleaved in one process, all bit-identical).
+// gate_proj [2048 x 4096 x 11008] / 8192 tokens / q_proj [2048 x 4096 x 4096], us:
+//   0: 128 x 128, 4 waves, one LDS stage of 128 B of K, ~3 workgroups per CU                      122 / 472 / 48     (<= 128 tokens)
+//   1: 128 x 128, two stages (next step's DMA under the matrix work), 2 workgroups per CU           127 / 536 / 47
+//   2: 256 x 256, 8 waves, two stages, 1 workgroup per CU                                           145 / 446 / 75
+//   3: 256 x 256, 8 waves, four-stage DMA ring of 64 B of K, counted waits                         110 / 363 / 55     (default when its tiles fill whole rounds)
+//   4: 256 x 128, the same ring                                                                      115 / 514 / 45
+//   5: 3 for whole rounds of the chip + 4 for the remaining columns, one launch                      96 / 353 / 45     (default otherwise)
+//   (256 x 128 and 128 x 256 with 8 waves in the two-stage form measured 10-25 % slower than variant 0 on every shape and were removed; so was a
+//    form with the weight fragments loaded straight into registers, 32 rows x 64 B per load instruction: 1.5x slower)
 struct MxCfg { int bm, bn; };
-constexpr MxCfg kMxCfg[] = {{128, 128}, {128, 128}, {256, 256}, {256, 256}, {256, 128}};
-constexpr int kMxVariants = 5;
+constexpr MxCfg kMxCfg[] = {{128, 128}, {128, 128}, {256, 256}, {256, 256}, {256, 128}, {256, 256}};
+constexpr int kMxVariants = 6;
 
 template <int OUT_DT>
 int launch_mx8(int variant, const uint8_t* a, const uint8_t* as, const uint8_t* b, const uint8_t* bs, const void* bias, void* out,
@@ -426,6 +459,18 @@ int launch_mx8(int variant, const uint8_t* a, const uint8_t* as, const uint8_t* 
     const int bm = kMxCfg[variant].bm, bn = kMxCfg[variant].bn;
     const int tiles_t = (T + bm - 1) / bm, tiles_n = (N + bn - 1) / bn;
     const dim3 grid((unsigned)(tiles_t * tiles_n));
+    if (variant == 5) {
+        // whole rounds of the chip in 256 x 256 tiles, the rest of the columns in 256 x 128 tiles (kCUs: the part has 256)
+        constexpr int kCUs = 256;
+        const int rounds = tiles_t * tiles_n / kCUs;
+        int big_cols = rounds > 0 ? rounds * kCUs / tiles_t : 0;               // column tiles of 256 that go as big tiles
+        if (big_cols > tiles_n) big_cols = tiles_n;
+        const int n_big = big_cols * tiles_t, n_base = big_cols * 256;
+        const int small_cols = n_base < N ? (N - n_base + 127) / 128 : 0;
+        const dim3 g2((unsigned)(n_big + small_cols * tiles_t));
+        hipLaunchKernelGGL((k_mx8_gemm_ring_mixed<OUT_DT>), g2, dim3(512), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t, n_big, n_base);
+        return (int)hipGetLastError();
+    }
     switch (variant) {
         case 0: hipLaunchKernelGGL((k_mx8_gemm<OUT_DT, 2, 2, 2, 2, false>), grid, dim3(256), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
         case 1: hipLaunchKernelGGL((k_mx8_gemm<OUT_DT, 2, 2, 2, 2, true>), grid, dim3(256), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
@@ -462,7 +507,7 @@ int bfpq_hbfp_linear_mx8_ok(int64_t T, int64_t N, int64_t K)
            ((T + 127) / 128) * ((N + 127) / 128) < ((int64_t)1 << 30);
 }
 
-__attribute__((visibility("hidden"))) int bfpq_g_mx8_variant = -1;             // -1 = choose; 0..2 force (bfpq_tune, BFPQ_TUNE_MX8_VARIANT)
+__attribute__((visibility("hidden"))) int bfpq_g_mx8_variant = -1;             // -1 = choose; 0..5 force (bfpq_tune, BFPQ_TUNE_MX8_VARIANT)
 
 int bfpq_hbfp_linear_mx8(const void* x8, const void* xs, const void* w8, const void* ws, const void* bias, void* out,
                          int64_t T, int64_t N, int64_t K, int out_dtype, void* stream)
@@ -474,7 +519,16 @@ int bfpq_hbfp_linear_mx8(const void* x8, const void* xs, const void* w8, const v
     if ((reinterpret_cast<uintptr_t>(x8) | reinterpret_cast<uintptr_t>(w8)) & 15u) return BFPQ_E_ARG;
     if ((reinterpret_cast<uintptr_t>(xs) | reinterpret_cast<uintptr_t>(ws)) & 3u) return BFPQ_E_ARG;
     int variant = bfpq_g_mx8_variant;
-    if (variant < 0 || variant >= kMxVariants) variant = ((T + 255) / 256) * ((N + 255) / 256) >= 1024 ? 2 : 0;
+    if (variant < 0 || variant >= kMxVariants) {
+        // rounds of the chip, measured: a 256 x 128 tile costs 0.70 of a 256 x 256 one, a partly filled last round 0.72 of a full one
+        // (gate_proj 2048 tokens: all-big 1.72 -> 110 us, mixed 1.5 -> 96 us; 13B gate_proj: all-big 1.72 -> 137 us, mixed 2.2 -> 161 us)
+        const int64_t tt = (T + 255) / 256, tn = (N + 255) / 256, tiles = tt * tn, R = tiles / 256;
+        const int64_t big_cols = R > 0 ? (R * 256 / tt < tn ? R * 256 / tt : tn) : 0;
+        const int64_t n_small = big_cols * 256 < N ? (N - big_cols * 256 + 127) / 128 * tt : 0;
+        const double est_big = (double)R + (tiles % 256 ? 0.72 : 0.0);
+        const double est_mixed = (double)(big_cols * tt) / 256.0 + 0.70 * ((double)(n_small / 256) + (n_small % 256 ? 0.72 : 0.0));
+        variant = T <= 128 ? 0 : (est_big <= est_mixed ? 3 : 5);
+    }
     hipStream_t s = (hipStream_t)stream;
     const uint8_t *a = (const uint8_t*)x8, *as = (const uint8_t*)xs, *b = (const uint8_t*)w8, *bs = (const uint8_t*)ws;
     if (out_dtype == BFPQ_F32) return launch_mx8<BFPQ_F32>(variant, a, as, b, bs, bias, out, (int)T, (int)N, (int)K, s);
