@@ -262,50 +262,59 @@ __global__ void __launch_bounds__(64 * WM * WN) k_mx8_gemm(const uint8_t* __rest
 //   LDS rows are 64 bytes = 4 slots of 16; slot' = slot ^ ((row >> 2) & 3) on the DMA source and on the read spreads the 16 rows of
 //   a ds_read_b128 lane group over all 64 banks.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ v8i read_frag64(const uint8_t* tile, int row, int half)  // 32 bytes: slots 2 half, 2 half + 1 of a 64-byte row
+// 32 bytes of block b (of KB per LDS row), lane half `half`: slots 4 b + 2 half, + 1 of a row of 4 KB slots
+template <int KB>
+__device__ __forceinline__ v8i read_frag_ring(const uint8_t* tile, int row, int b, int half)
 {
-    const int sw = (row >> 2) & 3;
-    const v4i a0 = *reinterpret_cast<const v4i*>(tile + row * 64 + (((2 * half) ^ sw) << 4));
-    const v4i a1 = *reinterpret_cast<const v4i*>(tile + row * 64 + (((2 * half + 1) ^ sw) << 4));
+    const int sw = KB == 1 ? (row >> 2) & 3 : (row >> 1) & 7;
+    const int c = 4 * b + 2 * half;
+    const v4i a0 = *reinterpret_cast<const v4i*>(tile + row * (64 * KB) + ((c ^ sw) << 4));
+    const v4i a1 = *reinterpret_cast<const v4i*>(tile + row * (64 * KB) + (((c + 1) ^ sw) << 4));
     return v8i{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 }
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int WM, int WN, int TM, int TN> struct RingCfg {
-    static constexpr int NW = WM * WN, NT = 64 * NW, BM = 32 * WM * TM, BN = 32 * WN * TN, STAGE = (BM + BN) * 64, NS = 4;
+// KB = HBFP blocks (64 B of K) per ring stage, NS = stages in the ring (the DMA runs NS - 1 stages ahead)
+template <int WM, int WN, int TM, int TN, int KB, int NS> struct RingCfg {
+    static constexpr int NW = WM * WN, NT = 64 * NW, BM = 32 * WM * TM, BN = 32 * WN * TN, STAGE = (BM + BN) * 64 * KB;
     static constexpr int LDS_BYTES = NS * STAGE + 2 * NT * 4;
 };
 
 // one output tile: `orig` of `nwg` workgroups of this tile shape (ids remapped per XCD), columns starting at n_base
-template <int OUT_DT, int WM, int WN, int TM, int TN>
+template <int OUT_DT, int WM, int WN, int TM, int TN, int KB, int NS>
 __device__ __forceinline__ void ring_tile(uint8_t* lds, int orig, int nwg, int n_base,
                                           const uint8_t* __restrict__ x8, const uint8_t* __restrict__ xs, const uint8_t* __restrict__ w8,
                                           const uint8_t* __restrict__ wsc, const void* __restrict__ bias, void* __restrict__ out,
                                           int T, int N, int K, int tiles_t)
 {
-    using C = RingCfg<WM, WN, TM, TN>;
-    constexpr int NW = C::NW, NT = C::NT, BM = C::BM, BN = C::BN, STAGE = C::STAGE, NS = C::NS;
-    constexpr int GA = BM / 16 / NW, GB = BN / 16 / NW, G = GA + GB;           // DMA pieces (16 rows x 64 B = 1 KB) per wave and stage
-    static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "tile rows must split evenly over the waves");
+    using C = RingCfg<WM, WN, TM, TN, KB, NS>;
+    constexpr int NW = C::NW, NT = C::NT, BM = C::BM, BN = C::BN, STAGE = C::STAGE;
+    constexpr int RPP = 16 / KB, SLOTS = 4 * KB;                               // tile rows per DMA piece (1 KB), 16-byte slots per row
+    constexpr int GA = BM / RPP / NW, GB = BN / RPP / NW, G = GA + GB;         // DMA pieces per wave and stage
+    constexpr int D = NS - 1, SPT = 4 / KB;                                    // stages the DMA runs ahead; stages per trip of 4 blocks (one scale dword)
+    static_assert(KB == 1 || KB == 2, "one or two blocks per stage");
+    static_assert(D >= 1 && D <= SPT, "the next trip's scales must have landed when the trip begins");
+    static_assert(BM % (RPP * NW) == 0 && BN % (RPP * NW) == 0, "tile rows must split evenly over the waves");
     static_assert(NT >= BM + BN, "one thread per tile row carries the row's scales");
     uint8_t* const sscale = lds + NS * STAGE;                                  // [2][NT] dwords: scales of the 4 blocks of a trip, per tile row
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     const int t0 = (wg % tiles_t) * BM, n0 = n_base + (wg / tiles_t) * BN;
-    const int nb = K >> 6, S = nb, trips = nb >> 2;
+    const int nb = K >> 6, S = nb / KB, trips = nb >> 2;
 
+    auto swz = [](int row) { return KB == 1 ? (row >> 2) & 3 : (row >> 1) & 7; };
     size_t offA[GA], offB[GB];
 #pragma unroll
     for (int i = 0; i < GA; i++) {
-        const int row = (NW * i + w) * 16 + (l >> 2), piece = ((l & 3) ^ ((row >> 2) & 3)) << 4;
+        const int row = (NW * i + w) * RPP + l / SLOTS, piece = ((l % SLOTS) ^ swz(row)) << 4;
         const int ta = t0 + row < T ? t0 + row : T - 1;
         offA[i] = (size_t)ta * K + piece;
     }
 #pragma unroll
     for (int i = 0; i < GB; i++) {
-        const int row = (NW * i + w) * 16 + (l >> 2), piece = ((l & 3) ^ ((row >> 2) & 3)) << 4;
+        const int row = (NW * i + w) * RPP + l / SLOTS, piece = ((l % SLOTS) ^ swz(row)) << 4;
         const int na = n0 + row < N ? n0 + row : N - 1;
         offB[i] = (size_t)na * K + piece;
     }
@@ -326,10 +335,10 @@ __device__ __forceinline__ void ring_tile(uint8_t* lds, int orig, int nwg, int n
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
 
-    auto stage = [&](int s, int buf) __attribute__((always_inline)) {           // block s of K -> ring slot buf
+    auto stage = [&](int s, int buf) __attribute__((always_inline)) {           // stage s of K (KB blocks) -> ring slot buf
         uint8_t* const sA = lds + buf * STAGE;
-        uint8_t* const sB = sA + BM * 64;
-        const int k0 = s << 6;
+        uint8_t* const sB = sA + BM * 64 * KB;
+        const int k0 = s * (64 * KB);
 #pragma unroll
         for (int i = 0; i < GA; i++)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x8 + offA[i] + k0),
@@ -343,56 +352,56 @@ __device__ __forceinline__ void ring_tile(uint8_t* lds, int orig, int nwg, int n
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srow + trip),
                                          (__attribute__((address_space(3))) void*)(sscale + (trip & 1) * NT * 4 + w * 256), 4, 0, 0);
     };
-    auto hand_over = [&](auto n_tag) __attribute__((always_inline)) {           // counted wait, then the raw barrier
-        wait_vm<decltype(n_tag)::value>();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    };
     int sa[TM], sb[TN];
-    auto mm = [&](auto op_tag, int buf) __attribute__((always_inline)) {
+    auto mm = [&](auto op_tag, int buf, int b) __attribute__((always_inline)) {
         constexpr int OP = decltype(op_tag)::value;
         const uint8_t* const sA = lds + buf * STAGE;
-        const uint8_t* const sB = sA + BM * 64;
+        const uint8_t* const sB = sA + BM * 64 * KB;
         v8i aF[TM], bF[TN];
 #pragma unroll
-        for (int i = 0; i < TM; i++) aF[i] = read_frag64(sA, rowA + 32 * i, half);
+        for (int i = 0; i < TM; i++) aF[i] = read_frag_ring<KB>(sA, rowA + 32 * i, b, half);
 #pragma unroll
-        for (int j = 0; j < TN; j++) bF[j] = read_frag64(sB, rowB + 32 * j, half);
+        for (int j = 0; j < TN; j++) bF[j] = read_frag_ring<KB>(sB, rowB + 32 * j, b, half);
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int j = 0; j < TN; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(aF[i], bF[j], acc[i][j], 0, 0, OP, sa[i], OP, sb[j]);
     };
-    template_int<0> I0; template_int<1> I1; template_int<2> I2; template_int<3> I3;
+    // step j of a trip, working on stage s in ring slot `slot`: [j == 0: the next trip's scales,] the DMA of stage s + D, the matrix work of
+    // stage s, then the hand-over: stage s + 1 must have landed, i.e. all but the (D - 1) G pieces of stages s+2 .. s+D (and the scale dword while
+    // it still sits behind stage s + 1 in the queue: j <= D - 2) may stay in flight; then the raw barrier.
+    auto step = [&](auto j_tag, int s, int& slot, int trn) __attribute__((always_inline)) {
+        constexpr int J = decltype(j_tag)::value;
+        if constexpr (J == 0) stage_scales(trn);
+        int pslot = slot + D; if (pslot >= NS) pslot -= NS;
+        stage(s + D < S ? s + D : S - 1, pslot);
+        mm(template_int<J * KB>{}, slot, 0);
+        if constexpr (KB == 2) mm(template_int<J * KB + 1>{}, slot, 1);
+        wait_vm<(D - 1) * G + (J <= D - 2 ? 1 : 0)>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        slot = slot + 1 == NS ? 0 : slot + 1;
+    };
 
-    // prologue: scales of trip 0 and blocks 0, 1, 2 (S >= 4 since K % 256 == 0), drained once
+    // prologue: scales of trip 0 and stages 0 .. D-1, drained once
     stage_scales(0);
-    stage(0, 0); stage(1, 1); stage(2, 2);
+#pragma unroll
+    for (int d = 0; d < D; d++) stage(d, d);
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
+    int slot = 0;
     for (int tr = 0; tr < trips; tr++) {
-        const int s = tr << 2;
+        const int s = tr * SPT;
         const int trn = tr + 1 < trips ? tr + 1 : tr;
         const uint32_t* const sc = reinterpret_cast<const uint32_t*>(sscale + (tr & 1) * NT * 4);
 #pragma unroll
         for (int i = 0; i < TM; i++) sa[i] = (int)sc[rowA + 32 * i];
 #pragma unroll
         for (int j = 0; j < TN; j++) sb[j] = (int)sc[BM + rowB + 32 * j];
-        // queue (issue order) at each hand-over: ... [s+1][s+2][scales][s+3] | [s+2][scales][s+3][s+4] | [s+3][s+4][s+5] | [s+4][s+5][s+6]
-        stage_scales(trn);
-        stage(s + 3 < S ? s + 3 : S - 1, 3);
-        mm(I0, 0);
-        hand_over(template_int<2 * G + 1>{});                                   // block s+1 landed
-        stage(s + 4 < S ? s + 4 : S - 1, 0);
-        mm(I1, 1);
-        hand_over(template_int<2 * G + 1>{});                                   // block s+2 landed (the scale dword sits behind it)
-        stage(s + 5 < S ? s + 5 : S - 1, 1);
-        mm(I2, 2);
-        hand_over(template_int<2 * G>{});                                       // block s+3 and the next trip's scales landed
-        stage(s + 6 < S ? s + 6 : S - 1, 2);
-        mm(I3, 3);
-        hand_over(template_int<2 * G>{});                                       // block s+4 landed
+        step(template_int<0>{}, s, slot, trn);
+        if constexpr (SPT > 1) step(template_int<1>{}, s + 1, slot, trn);
+        if constexpr (SPT > 2) { step(template_int<2>{}, s + 2, slot, trn); step(template_int<3>{}, s + 3, slot, trn); }
     }
     wait_vm<0>();                                                               // (the clamped re-stages of the tail)
 
@@ -413,41 +422,42 @@ __device__ __forceinline__ void ring_tile(uint8_t* lds, int orig, int nwg, int n
     }
 }
 
-template <int OUT_DT, int WM, int WN, int TM, int TN>
+template <int OUT_DT, int WM, int WN, int TM, int TN, int KB, int NS>
 __global__ void __launch_bounds__(64 * WM * WN) k_mx8_gemm_ring(const uint8_t* __restrict__ x8, const uint8_t* __restrict__ xs, const uint8_t* __restrict__ w8,
                                                                 const uint8_t* __restrict__ wsc, const void* __restrict__ bias, void* __restrict__ out,
                                                                 int T, int N, int K, int tiles_t)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[RingCfg<WM, WN, TM, TN>::LDS_BYTES];
-    ring_tile<OUT_DT, WM, WN, TM, TN>(lds, (int)blockIdx.x, (int)gridDim.x, 0, x8, xs, w8, wsc, bias, out, T, N, K, tiles_t);
+    __shared__ __attribute__((aligned(16))) uint8_t lds[RingCfg<WM, WN, TM, TN, KB, NS>::LDS_BYTES];
+    ring_tile<OUT_DT, WM, WN, TM, TN, KB, NS>(lds, (int)blockIdx.x, (int)gridDim.x, 0, x8, xs, w8, wsc, bias, out, T, N, K, tiles_t);
 }
 
 // Two tile shapes in one launch.  256 x 256 tiles need half the operand bytes per flop, but N / 256 x T / 256 of them rarely fill
 // the 256 CUs a whole number of times (2048 tokens x 11008 features: 344 tiles = one full round and a third of a second one).  So
 // the first n_big workgroups (whole rounds of the chip) take 256 x 256 tiles of the first columns, the remaining columns go in
 // 256 x 128 tiles, which are dispatched last and fill the CUs as the big tiles retire.
-template <int OUT_DT>
+template <int OUT_DT, int SKB, int SNS>
 __global__ void __launch_bounds__(512) k_mx8_gemm_ring_mixed(const uint8_t* __restrict__ x8, const uint8_t* __restrict__ xs, const uint8_t* __restrict__ w8,
                                                              const uint8_t* __restrict__ wsc, const void* __restrict__ bias, void* __restrict__ out,
                                                              int T, int N, int K, int tiles_t, int n_big, int n_base_small)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t lds[RingCfg<2, 4, 4, 2>::LDS_BYTES];
+    constexpr int LB = RingCfg<2, 4, 4, 2, 1, 4>::LDS_BYTES, LS = RingCfg<4, 2, 2, 2, SKB, SNS>::LDS_BYTES;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LB > LS ? LB : LS];
     if ((int)blockIdx.x < n_big)
-        ring_tile<OUT_DT, 2, 4, 4, 2>(lds, (int)blockIdx.x, n_big, 0, x8, xs, w8, wsc, bias, out, T, N, K, tiles_t);
+        ring_tile<OUT_DT, 2, 4, 4, 2, 1, 4>(lds, (int)blockIdx.x, n_big, 0, x8, xs, w8, wsc, bias, out, T, N, K, tiles_t);
     else
-        ring_tile<OUT_DT, 4, 2, 2, 2>(lds, (int)blockIdx.x - n_big, (int)gridDim.x - n_big, n_base_small, x8, xs, w8, wsc, bias, out, T, N, K, tiles_t);
+        ring_tile<OUT_DT, 4, 2, 2, 2, SKB, SNS>(lds, (int)blockIdx.x - n_big, (int)gridDim.x - n_big, n_base_small, x8, xs, w8, wsc, bias, out, T, N, K, tiles_t);
 }
 
 // Tile variants (bfpq_tune key BFPQ_TUNE_MX8_VARIANT; measured with tools_dev/ab_mx8.py, interleaved in one process, all bit-identical).
-// gate_proj [2048 x 4096 x 11008] / 8192 tokens / q_proj [2048 x 4096 x 4096], us:
-//   0: 128 x 128, 4 waves, one LDS stage of 128 B of K, ~3 workgroups per CU                      122 / 472 / 48     (<= 128 tokens)
-//   1: 128 x 128, two stages (next step's DMA under the matrix work), 2 workgroups per CU           127 / 536 / 47
-//   2: 256 x 256, 8 waves, two stages, 1 workgroup per CU                                           145 / 446 / 75
-//   3: 256 x 256, 8 waves, four-stage DMA ring of 64 B of K, counted waits                         110 / 363 / 55     (default when its tiles fill whole rounds)
-//   4: 256 x 128, the same ring                                                                      115 / 514 / 45
-//   5: 3 for whole rounds of the chip + 4 for the remaining columns, one launch                      96 / 353 / 45     (default otherwise)
-//   (256 x 128 and 128 x 256 with 8 waves in the two-stage form measured 10-25 % slower than variant 0 on every shape and were removed; so was a
-//    form with the weight fragments loaded straight into registers, 32 rows x 64 B per load instruction: 1.5x slower)
+// gate_proj [2048 x 4096 x 11008] / 8192 tokens / q_proj [2048 x 4096 x 4096] / down_proj [2048 x 11008 x 4096], us:
+//   0: 128 x 128, 4 waves, one LDS stage of 128 B of K, ~3 workgroups per CU                      119 / 469 / 49 / 108   (<= 128 tokens)
+//   1: 128 x 128, two stages (next step's DMA under the matrix work), 2 workgroups per CU           127 / 536 / 47 / 109
+//   2: 256 x 256, 8 waves, two stages, 1 workgroup per CU                                           145 / 446 / 75 / 161
+//   3: 256 x 256, 8 waves, ring of four stages of 64 B of K, counted waits                         109 / 360 / 55 / 129   (default when its tiles fill whole rounds)
+//   4: 256 x 128, 8 waves, ring of three stages of 128 B of K                                        95 / 487 / 38 /  86
+//   5: 3 for whole rounds of the chip + 4 for the remaining columns, one launch                      90 / 389 / 37 /  86   (default otherwise)
+//   (a 256 x 128 ring with 64-byte stages -- four matrix instructions per barrier -- ran 113 / 515 / 45 / 106; 256 x 128 and 128 x 256 in the
+//    two-stage form 10-25 % behind variant 0; weight fragments loaded straight into registers, 32 rows x 64 B per load instruction, 1.5x slower: removed)
 struct MxCfg { int bm, bn; };
 constexpr MxCfg kMxCfg[] = {{128, 128}, {128, 128}, {256, 256}, {256, 256}, {256, 128}, {256, 256}};
 constexpr int kMxVariants = 6;
@@ -468,15 +478,15 @@ int launch_mx8(int variant, const uint8_t* a, const uint8_t* as, const uint8_t* 
         const int n_big = big_cols * tiles_t, n_base = big_cols * 256;
         const int small_cols = n_base < N ? (N - n_base + 127) / 128 : 0;
         const dim3 g2((unsigned)(n_big + small_cols * tiles_t));
-        hipLaunchKernelGGL((k_mx8_gemm_ring_mixed<OUT_DT>), g2, dim3(512), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t, n_big, n_base);
+        hipLaunchKernelGGL((k_mx8_gemm_ring_mixed<OUT_DT, 2, 3>), g2, dim3(512), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t, n_big, n_base);
         return (int)hipGetLastError();
     }
     switch (variant) {
         case 0: hipLaunchKernelGGL((k_mx8_gemm<OUT_DT, 2, 2, 2, 2, false>), grid, dim3(256), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
         case 1: hipLaunchKernelGGL((k_mx8_gemm<OUT_DT, 2, 2, 2, 2, true>), grid, dim3(256), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
         case 2: hipLaunchKernelGGL((k_mx8_gemm<OUT_DT, 2, 4, 4, 2, true>), grid, dim3(512), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
-        case 3: hipLaunchKernelGGL((k_mx8_gemm_ring<OUT_DT, 2, 4, 4, 2>), grid, dim3(512), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
-        default: hipLaunchKernelGGL((k_mx8_gemm_ring<OUT_DT, 4, 2, 2, 2>), grid, dim3(512), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
+        case 3: hipLaunchKernelGGL((k_mx8_gemm_ring<OUT_DT, 2, 4, 4, 2, 1, 4>), grid, dim3(512), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
+        default: hipLaunchKernelGGL((k_mx8_gemm_ring<OUT_DT, 4, 2, 2, 2, 2, 3>), grid, dim3(512), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
     }
     return (int)hipGetLastError();
 }
@@ -520,14 +530,15 @@ int bfpq_hbfp_linear_mx8(const void* x8, const void* xs, const void* w8, const v
     if ((reinterpret_cast<uintptr_t>(xs) | reinterpret_cast<uintptr_t>(ws)) & 3u) return BFPQ_E_ARG;
     int variant = bfpq_g_mx8_variant;
     if (variant < 0 || variant >= kMxVariants) {
-        // rounds of the chip, measured: a 256 x 128 tile costs 0.70 of a 256 x 256 one, a partly filled last round 0.72 of a full one
-        // (gate_proj 2048 tokens: all-big 1.72 -> 110 us, mixed 1.5 -> 96 us; 13B gate_proj: all-big 1.72 -> 137 us, mixed 2.2 -> 161 us)
+        // rounds of the chip, measured: a 256 x 128 tile costs 0.60 of a 256 x 256 one, a partly filled last round 0.72 of a full one
+        // (gate_proj 2048 tokens: all-big 1.72 -> 109 us, mixed 1.43 -> 90 us; 13B gate_proj: all-big 1.72 -> 136 us, mixed 2.03 -> 147 us;
+        //  8192 tokens: all-big 5.72 -> 360 us, mixed 5.43 -> 389 us: the estimate flatters the mixed plan by ~8 %, hence the margin)
         const int64_t tt = (T + 255) / 256, tn = (N + 255) / 256, tiles = tt * tn, R = tiles / 256;
         const int64_t big_cols = R > 0 ? (R * 256 / tt < tn ? R * 256 / tt : tn) : 0;
         const int64_t n_small = big_cols * 256 < N ? (N - big_cols * 256 + 127) / 128 * tt : 0;
         const double est_big = (double)R + (tiles % 256 ? 0.72 : 0.0);
-        const double est_mixed = (double)(big_cols * tt) / 256.0 + 0.70 * ((double)(n_small / 256) + (n_small % 256 ? 0.72 : 0.0));
-        variant = T <= 128 ? 0 : (est_big <= est_mixed ? 3 : 5);
+        const double est_mixed = (double)(big_cols * tt) / 256.0 + 0.60 * ((double)(n_small / 256) + (n_small % 256 ? 0.72 : 0.0));
+        variant = T <= 128 ? 0 : (est_mixed < 0.92 * est_big ? 5 : 3);
     }
     hipStream_t s = (hipStream_t)stream;
     const uint8_t *a = (const uint8_t*)x8, *as = (const uint8_t*)xs, *b = (const uint8_t*)w8, *bs = (const uint8_t*)ws;
