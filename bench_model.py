@@ -48,6 +48,7 @@ def main():
     models["plain"] = copy.deepcopy(base).to("cuda:0")
     m = copy.deepcopy(base); patch_linear_layers(m, args); models["BFPLinear (reference semantics)"] = m.to("cuda:0")
     m = copy.deepcopy(base); patch_linear_layers(m, args, cache_weights=True); models["BFPLinear + weight cache"] = m.to("cuda:0")
+    m = copy.deepcopy(base); patch_linear_layers(m, args, cache_weights=True, matrix_unit=True); models["BFPLinear + weight cache + matrix unit"] = m.to("cuda:0")
     m = copy.deepcopy(base).to("cuda:0"); pack_linear_layers(m, args); models["PackedBFPLinear (4-bit weights)"] = m
     rows = []
     for tokens, iters in ((1, 20), (16, 20), (2048, 3)):

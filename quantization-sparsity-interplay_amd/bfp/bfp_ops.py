@@ -442,13 +442,20 @@ class WeightCache:
     which does not bump the version counter), and for stochastic rounding.  After such an update in eval mode call
     invalidate()."""
 
-    def __init__(self, module=None):
+    def __init__(self, module=None, matrix_unit=False):
         import weakref
         self.key = None
         self.value = None
         self.hits = 0
         self.misses = 0
         self._module = weakref.ref(module) if module is not None else None
+        # matrix_unit: F.linear on the two fake-quantised operands is replaced by the block-scaled matrix instruction on their e4m3 + E8M0
+        # images where the configuration allows it (same products and block sums, fp32 across blocks; see PackedBFP.linear); the weight's
+        # image is cached like the fake-quantised weight, under the same key
+        self.matrix_unit = bool(matrix_unit)
+        self.image_key = None
+        self.image = None
+        self.mx_calls = 0
 
     @staticmethod
     def _key(w, bfp_args):
@@ -481,6 +488,20 @@ class WeightCache:
     def invalidate(self):
         self.key = None
         self.value = None
+        self.image_key = None
+        self.image = None
+
+    def weight_image(self, w, bfp_args):
+        """e4m3 + E8M0 image of Q_w(w) for the matrix unit, made from the packed codes of the weight (not from the fake-quantised
+        tensor: HBFP quantization is not idempotent on a block whose maximum rounded down to a power of two)"""
+        key = self._key(w, bfp_args)
+        if self.image_key != key:
+            a = bfp_args
+            sp = a['w_sparsity'] == True  # noqa: E712
+            codes, exps = float_to_bfp_packed(w.detach(), a['mant_bits'], 64, a['epsilon'], a['N'] if sp else 0, a['M'] if sp else 0, a['first'], 4)
+            self.image = native.mx8_from_hbfp(codes, exps, w.shape[-1], a['mant_bits'], 4)
+            self.image_key = key
+        return self.image
 
 
 def _pair_in_one_launch(x, w, bfp_args):
@@ -548,11 +569,30 @@ class _GradQuantizer(torch.autograd.Function):
         return float_to_bfp_blocked(grad_out, **ctx.bfp_args, identifier='grad'), None
 
 
+def _matrix_unit_ok(x, w, a, cache):
+    """the cached Linear forward can run on the block-scaled matrix instruction: HBFP with block 64 and <= 3 mantissa bits (4-bit codes),
+    round-half-even, dense activations, dense or N:M weights, a 2-D weight with K % 256 == 0, enough tokens to fill a tile row"""
+    if (a['num_format'] != 'bfp' or a['sparsity_num_format'] != 'bfp' or a['block_size'] != 64 or not (1 <= a['mant_bits'] <= 3)
+            or a['rounding_mode'] != rounding_modes.DETERM or a['in_sparsity'] == True or w.dim() != 2 or x.device.type != 'cuda'  # noqa: E712
+            or torch.compiler.is_compiling() or not cache.usable(w, a)):
+        return False
+    if a['w_sparsity'] == True and (a['sparsity_mode'] != 'structured' or not (0 < a['N'] <= a['M']) or a['M'] not in (2, 4, 8)):  # noqa: E712
+        return False
+    K = x.shape[-1]
+    T = x.numel() // K if K else 0
+    return T >= 32 and native.hbfp_linear_mx8_ok(T, w.shape[0], K, a['mant_bits'], a['mant_bits'], 64)
+
+
 def _gen_bfp_op(op, name, bfp_args, transpose=False, cache=None):
     """reference: bfp_ops.py:160-192 -- wraps `op(x, w, ...)` so that both operands are BFP-quantized
     (and sparsified) on the way in and the output gradient on the way back.  cache: optional WeightCache."""
     def bfp_op(x, w, *args, **kwargs):
         if not torch.is_grad_enabled():                 # inference: same values, no autograd nodes to build
+            if cache is not None and cache.matrix_unit and op is F.linear and _matrix_unit_ok(x, w, bfp_args, cache):
+                cache.mx_calls += 1
+                bias = args[0] if args else kwargs.get('bias')
+                w8, wsc = cache.weight_image(w, bfp_args)
+                return native.hbfp_linear_mx8(x, w8, wsc, bfp_args['mant_bits'], bfp_args['epsilon'], bias=bias)
             xq, wq = _quantize_operands(x, w, transpose, bfp_args, cache)
             return op(xq, wq, *args, **kwargs)
         xq, wq = _OperandQuantizer.apply(x, w, transpose, bfp_args, cache)
@@ -604,9 +644,12 @@ class _BFPModule:
         self.num_format = self.bfp_args['num_format']
         return _get_bfp_op(self._functional, self._op_name, self.bfp_args)
 
-    def enable_weight_cache(self, enabled=True):
-        """opt in to (or out of) caching the quantized weight across forwards; see WeightCache"""
-        cache = WeightCache(self) if enabled else None
+    def enable_weight_cache(self, enabled=True, matrix_unit=False):
+        """opt in to (or out of) caching the quantized weight across forwards; see WeightCache.  matrix_unit=True additionally
+        runs the Linear itself on the block-scaled matrix instruction where the configuration allows (HBFP4-class, block 64,
+        >= 32 tokens): the same block products, summed exactly inside a block and in fp32 across blocks instead of by the bf16
+        library GEMM -- results agree with F.linear on the fake-quantised operands up to that summation order."""
+        cache = WeightCache(self, matrix_unit=matrix_unit) if enabled else None
         op = _get_bfp_op(self._functional, self._op_name, self.bfp_args, cache=cache)
         if hasattr(self, 'linear_op'):
             self.linear_op = op

@@ -407,6 +407,37 @@ __device__ __forceinline__ void ring_tile(uint8_t* lds, int orig, int nwg, int n
 
     using raw_t = typename Traits<OUT_DT>::raw_t;
     raw_t* const o = reinterpret_cast<raw_t*>(out);
+    constexpr int ES = (int)sizeof(raw_t), EPP = 16 / ES;                       // bytes per element, elements per 16-byte piece
+    const bool vec_ok = (N % EPP) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+    if (vec_ok) {
+        // D has the output column on the lane and the rows in the registers: stored as it lies, every store instruction writes 2-byte
+        // elements in 64-byte runs (128 store instructions per wave for the 256 x 256 tile).  Each 32 x 32 instruction tile goes through
+        // a wave-private LDS patch instead (the ring is free by now) and leaves as 16-byte pieces, 64 contiguous bytes per row.
+        __builtin_amdgcn_s_barrier();                                           // every wave's DMA has landed: the ring may be overwritten
+        constexpr int RS = 32 * ES + 16;                                        // patch row stride: +16 bytes keeps lanes l and l+32 (rows r, r+4) on different banks
+        uint8_t* const ep = lds + w * (32 * RS);
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const int nl = n0 + wc * (32 * TN) + 32 * j + (l & 31);
+            const float bv = (bias && nl < N) ? raw_to_f32<OUT_DT>((uint32_t)reinterpret_cast<const raw_t*>(bias)[nl]) : 0.0f;
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int rr = (e & 3) + 8 * (e >> 2) + 4 * half;
+                    *reinterpret_cast<raw_t*>(ep + rr * RS + (l & 31) * ES) = (raw_t)f32_to_raw<OUT_DT>(acc[i][j][e] + bv);
+                }
+#pragma unroll
+                for (int qq = 0; qq < ES; qq++) {                               // 64 ES pieces of 16 bytes per tile: ES per lane
+                    const int pc = l + 64 * qq, rr = pc / (2 * ES), cp = pc % (2 * ES);
+                    const uint4 v = *reinterpret_cast<const uint4*>(ep + rr * RS + cp * 16);
+                    const int t = t0 + wr * (32 * TM) + 32 * i + rr, n = n0 + wc * (32 * TN) + 32 * j + cp * EPP;
+                    if (t < T && n < N) *reinterpret_cast<uint4*>(o + (size_t)t * N + n) = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int n = n0 + wc * (32 * TN) + 32 * j + (l & 31);
@@ -456,7 +487,8 @@ __global__ void __launch_bounds__(512) k_mx8_gemm_ring_mixed(const uint8_t* __re
 //   3: 256 x 256, 8 waves, ring of four stages of 64 B of K, counted waits                         109 / 360 / 55 / 129   (default when its tiles fill whole rounds)
 //   4: 256 x 128, 8 waves, ring of three stages of 128 B of K                                        95 / 487 / 38 /  86
 //   5: 3 for whole rounds of the chip + 4 for the remaining columns, one launch                      90 / 389 / 37 /  86   (default otherwise)
-//   (a 256 x 128 ring with 64-byte stages -- four matrix instructions per barrier -- ran 113 / 515 / 45 / 106; 256 x 128 and 128 x 256 in the
+//   (the ring's epilogue through a wave-private LDS patch, 16-byte stores: +1-3 % over lane-by-lane 2-byte stores; s_setprio(1) around the matrix
+//    instructions of a stage: -5...15 %, removed; a 256 x 128 ring with 64-byte stages -- four matrix instructions per barrier -- ran 113 / 515 / 45 / 106; 256 x 128 and 128 x 256 in the
 //    two-stage form 10-25 % behind variant 0; weight fragments loaded straight into registers, 32 rows x 64 B per load instruction, 1.5x slower: removed)
 struct MxCfg { int bm, bn; };
 constexpr MxCfg kMxCfg[] = {{128, 128}, {128, 128}, {256, 256}, {256, 256}, {256, 128}, {256, 256}};

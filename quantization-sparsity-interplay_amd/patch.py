@@ -9,7 +9,7 @@ import torch
 from .bfp import bfp_ops
 
 
-def patch_linear_layers(model, bfp_args, skip=("lm_head", "classifier", "score"), convs=False, cache_weights=False):
+def patch_linear_layers(model, bfp_args, skip=("lm_head", "classifier", "score"), convs=False, cache_weights=False, matrix_unit=False):
     """Replace nn.Linear children by bfp_ops.BFPLinear(**bfp_args) that reuse weight / bias.  Modules whose
     qualified name ends with an entry of `skip` stay as they are (the reference leaves the LM heads alone).
     Returns the list of patched module names."""
@@ -31,7 +31,7 @@ def patch_linear_layers(model, bfp_args, skip=("lm_head", "classifier", "score")
             new.bias = child.bias
             new.train(child.training)
             if cache_weights:
-                new.enable_weight_cache()
+                new.enable_weight_cache(matrix_unit=matrix_unit and isinstance(new, bfp_ops.BFPLinear))
             setattr(parent, child_name, new)
             patched.append(full)
     return patched

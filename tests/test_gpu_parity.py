@@ -825,6 +825,45 @@ def test_quantize_mx8_equals_codes_then_image(dname, xm):
     assert torch.equal(val[ok], want[ok])
 
 
+@pytest.mark.parametrize("dname", ["bf16", "f32"])
+def test_bfplinear_cached_on_the_matrix_unit(dname):
+    """opt-in enable_weight_cache(matrix_unit=True): the reference's module (bfp_ops.py:270-287) with its Linear on the block-scaled
+    matrix instruction -- against the fp64 product of the oracle-pinned fake-quantised operands, and against the module's ordinary
+    forward; short inputs, training mode and unsupported configurations keep the ordinary route"""
+    dt = DT[dname]
+    c = cfg(mant_bits=3, block_size=64, w_sparsity=True, N=2, M=4)
+    lin = bfp_ops.BFPLinear(512, 384, True, **dict(c)).to(DEV).to(dt).eval()
+    with torch.no_grad():
+        lin.weight.copy_(synth(384, 512, dt).to(DEV)); lin.bias.copy_(synth(1, 384, dt, 1.0, seed=5).view(384).to(DEV))
+    x = synth(3 * 50, 512, dt, 1.0, seed=11).view(3, 50, 512).to(DEV)
+    with torch.no_grad():
+        ref = lin(x)                                                      # F.linear on the two fake-quantised operands
+        lin.enable_weight_cache(matrix_unit=True)
+        got = lin(x)
+        cache = lin.linear_op.weight_cache
+        assert cache.mx_calls == 1 and got.shape == ref.shape and got.dtype == dt
+        xq = bfp_ops.float_to_bfp_blocked(x, **c, identifier='in').double().cpu().view(-1, 512)
+        wq = bfp_ops.float_to_bfp_blocked(lin.weight, **c, identifier='w').double().cpu()
+        want = (xq @ wq.t() + lin.bias.double().cpu()).view(3, 50, 384)
+        tol = {"f32": 2e-6, "bf16": 6e-3}[dname]
+        assert float((got.double().cpu() - want).abs().max() / want.abs().max()) < tol
+        assert float((ref.double().cpu() - want).abs().max() / want.abs().max()) < max(tol, 2e-5)   # (the library GEMM: its own summation order)
+        got2 = lin(x)                                                     # weight image cached
+        assert cache.mx_calls == 2 and torch.equal(got, got2)
+        short = lin(x[:1, :8])                                            # 8 tokens: the ordinary route
+        assert cache.mx_calls == 2 and torch.equal(short, ref[:1, :8])
+        lin.weight.mul_(0.5)                                              # in-place update: new image
+        got3 = lin(x)
+        assert cache.mx_calls == 3 and not torch.equal(got3, got)
+        lin.train()
+        lin(x)
+        assert cache.mx_calls == 3                                        # training mode bypasses the cache altogether
+    lin8 = bfp_ops.BFPLinear(512, 384, False, **dict(cfg(mant_bits=7, block_size=64))).to(DEV).to(dt).eval().enable_weight_cache(matrix_unit=True)
+    with torch.no_grad():
+        lin8(x)
+    assert lin8.linear_op.weight_cache.mx_calls == 0                      # HBFP8 does not fit e4m3: ordinary route
+
+
 def test_dist_paths_with_the_native_engine_on_rccl():
     """dist.py end to end on the device with the HIP engine and RCCL (backend "nccl"), one rank: the gloo tests cover the
     multi-rank protocol with a stand-in engine, this covers the real kernels, streams and collectives behind the same
