@@ -8,6 +8,7 @@ sys.path.insert(0, ROOT)
 import torch
 import quantization_sparsity_interplay_amd as bfpq
 from quantization_sparsity_interplay_amd.bfp import bfp_ops
+from quantization_sparsity_interplay_amd import native
 
 
 def timeit(fn, iters=50, rounds=5):
@@ -41,10 +42,11 @@ def main():
             cached = timeit(lambda: lin(x))
             wq = timeit(lambda: bfp_ops.float_to_bfp_blocked(lin.weight, **cfg, identifier='w'))
             aq = timeit(lambda: bfp_ops.float_to_bfp_blocked(x, **cfg, identifier='in'))
-            packed = None
-            if tokens <= 64:
-                pw = bfp_ops.PackedBFP.quantize(lin.weight, 3, 64, N=2, M=4)
-                packed = timeit(lambda: pw.linear(x))
+            # from the packed weight: <= 64 tokens the integer block-dot-product kernel (HBFP8 activations), more tokens the block-scaled
+            # matrix instruction (HBFP4 activations, as the module's configuration says); every call quantizes its activation
+            native.SHARE_ACT_IMAGE = False
+            pw = bfp_ops.PackedBFP.quantize(lin.weight, 3, 64, N=2, M=4)
+            packed = timeit(lambda: pw.linear(x)) if tokens <= 64 else timeit(lambda: pw.linear(x, x_mant_bits=3))
         rows.append(dict(layer=name, tokens=tokens, in_features=fin, out_features=fout, f_linear_us=plain, bfplinear_us=ref,
                          bfplinear_cached_us=cached, weight_quant_us=wq, act_quant_us=aq, packed_decode_us=packed))
         print(rows[-1], flush=True)

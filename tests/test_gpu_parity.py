@@ -727,7 +727,7 @@ def test_packed_consumer_decode_linear(N, K, T, dname):
 
 
 @pytest.mark.parametrize("N,K,T,dname", [(256, 512, 200, "bf16"), (384, 768, 129, "bf16"), (1024, 1024, 300, "f16"), (200, 256, 1, "f32"),
-                                          (4096, 4096, 512, "bf16")])
+                                          (4096, 4096, 512, "bf16"), (100, 256, 130, "bf16"), (1500, 1280, 700, "bf16")])
 def test_packed_consumer_prefill_mx8(N, K, T, dname):
     """§8f next #3, prefill: out = Q(x) @ Q(W)^T for many tokens from the packed weight on the block-scaled matrix
     instruction (e4m3 mantissas + E8M0 block scales: exact block dot products, fp32 across blocks), against the same product of
