@@ -547,7 +547,7 @@ int bfpq_tune(int key, int value)
 {
     if (key == BFPQ_TUNE_MAX_GRID && value >= 1 && value <= 65535) { bfpq_g_max_grid = value; return 0; }
     if (key == BFPQ_TUNE_GEMM_ROW_TILES && (value == 0 || value == 1 || value == 2 || value == 4)) { bfpq_g_gemm_rt = value; return 0; }
-    if (key == BFPQ_TUNE_MX8_VARIANT && value >= -1 && value <= 5) { bfpq_g_mx8_variant = value; return 0; }
+    if (key == BFPQ_TUNE_MX8_VARIANT && value >= -1 && value <= 6) { bfpq_g_mx8_variant = value; return 0; }
     return BFPQ_E_ARG;
 }
 

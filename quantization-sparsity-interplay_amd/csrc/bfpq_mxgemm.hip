@@ -481,18 +481,20 @@ __global__ void __launch_bounds__(512) k_mx8_gemm_ring_mixed(const uint8_t* __re
 
 // Tile variants (bfpq_tune key BFPQ_TUNE_MX8_VARIANT; measured with tools_dev/ab_mx8.py, interleaved in one process, all bit-identical).
 // gate_proj [2048 x 4096 x 11008] / 8192 tokens / q_proj [2048 x 4096 x 4096] / down_proj [2048 x 11008 x 4096], us:
-//   0: 128 x 128, 4 waves, one LDS stage of 128 B of K, ~3 workgroups per CU                      119 / 469 / 49 / 108   (<= 128 tokens)
+//   0: 128 x 128, 4 waves, one LDS stage of 128 B of K, ~3 workgroups per CU                      119 / 469 / 49 / 108
 //   1: 128 x 128, two stages (next step's DMA under the matrix work), 2 workgroups per CU           127 / 536 / 47 / 109
 //   2: 256 x 256, 8 waves, two stages, 1 workgroup per CU                                           145 / 446 / 75 / 161
 //   3: 256 x 256, 8 waves, ring of four stages of 64 B of K, counted waits                         109 / 360 / 55 / 129   (default when its tiles fill whole rounds)
 //   4: 256 x 128, 8 waves, ring of three stages of 128 B of K                                        95 / 487 / 38 /  86
 //   5: 3 for whole rounds of the chip + 4 for the remaining columns, one launch                      90 / 389 / 37 /  86   (default otherwise)
+//   6: 128 x 128, 4 waves, ring of three stages of 128 B of K (default up to 256 tokens: 128 tokens x gate_proj 23 us, variant 0: 39, variant 4: 30;
+//      128 tokens x down_proj -- 32 tiles, K = 11008 -- 50 us: a split of K is what that shape wants)
 //   (the ring's epilogue through a wave-private LDS patch, 16-byte stores: +1-3 % over lane-by-lane 2-byte stores; s_setprio(1) around the matrix
 //    instructions of a stage: -5...15 %, removed; a 256 x 128 ring with 64-byte stages -- four matrix instructions per barrier -- ran 113 / 515 / 45 / 106; 256 x 128 and 128 x 256 in the
 //    two-stage form 10-25 % behind variant 0; weight fragments loaded straight into registers, 32 rows x 64 B per load instruction, 1.5x slower: removed)
 struct MxCfg { int bm, bn; };
-constexpr MxCfg kMxCfg[] = {{128, 128}, {128, 128}, {256, 256}, {256, 256}, {256, 128}, {256, 256}};
-constexpr int kMxVariants = 6;
+constexpr MxCfg kMxCfg[] = {{128, 128}, {128, 128}, {256, 256}, {256, 256}, {256, 128}, {256, 256}, {128, 128}};
+constexpr int kMxVariants = 7;
 
 template <int OUT_DT>
 int launch_mx8(int variant, const uint8_t* a, const uint8_t* as, const uint8_t* b, const uint8_t* bs, const void* bias, void* out,
@@ -518,6 +520,7 @@ int launch_mx8(int variant, const uint8_t* a, const uint8_t* as, const uint8_t* 
         case 1: hipLaunchKernelGGL((k_mx8_gemm<OUT_DT, 2, 2, 2, 2, true>), grid, dim3(256), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
         case 2: hipLaunchKernelGGL((k_mx8_gemm<OUT_DT, 2, 4, 4, 2, true>), grid, dim3(512), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
         case 3: hipLaunchKernelGGL((k_mx8_gemm_ring<OUT_DT, 2, 4, 4, 2, 1, 4>), grid, dim3(512), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
+        case 6: hipLaunchKernelGGL((k_mx8_gemm_ring<OUT_DT, 2, 2, 2, 2, 2, 3>), grid, dim3(256), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
         default: hipLaunchKernelGGL((k_mx8_gemm_ring<OUT_DT, 4, 2, 2, 2, 2, 3>), grid, dim3(512), 0, s, a, as, b, bs, bias, out, T, N, K, tiles_t); break;
     }
     return (int)hipGetLastError();
@@ -549,7 +552,7 @@ int bfpq_hbfp_linear_mx8_ok(int64_t T, int64_t N, int64_t K)
            ((T + 127) / 128) * ((N + 127) / 128) < ((int64_t)1 << 30);
 }
 
-__attribute__((visibility("hidden"))) int bfpq_g_mx8_variant = -1;             // -1 = choose; 0..5 force (bfpq_tune, BFPQ_TUNE_MX8_VARIANT)
+__attribute__((visibility("hidden"))) int bfpq_g_mx8_variant = -1;             // -1 = choose; 0..6 force (bfpq_tune, BFPQ_TUNE_MX8_VARIANT)
 
 int bfpq_hbfp_linear_mx8(const void* x8, const void* xs, const void* w8, const void* ws, const void* bias, void* out,
                          int64_t T, int64_t N, int64_t K, int out_dtype, void* stream)
@@ -570,7 +573,7 @@ int bfpq_hbfp_linear_mx8(const void* x8, const void* xs, const void* w8, const v
         const int64_t n_small = big_cols * 256 < N ? (N - big_cols * 256 + 127) / 128 * tt : 0;
         const double est_big = (double)R + (tiles % 256 ? 0.72 : 0.0);
         const double est_mixed = (double)(big_cols * tt) / 256.0 + 0.60 * ((double)(n_small / 256) + (n_small % 256 ? 0.72 : 0.0));
-        variant = T <= 128 ? 0 : (est_mixed < 0.92 * est_big ? 5 : 3);
+        variant = T <= 256 ? 6 : (est_mixed < 0.92 * est_big ? 5 : 3);
     }
     hipStream_t s = (hipStream_t)stream;
     const uint8_t *a = (const uint8_t*)x8, *as = (const uint8_t*)xs, *b = (const uint8_t*)w8, *bs = (const uint8_t*)ws;

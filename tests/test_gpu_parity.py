@@ -777,7 +777,7 @@ def test_packed_consumer_prefill_mx8(N, K, T, dname):
     # every tile variant walks K in the same order: bit-identical results
     try:
         ref = None
-        for v in (0, 1, 2, 3, 4, 5, -1):
+        for v in (0, 1, 2, 3, 4, 5, 6, -1):
             assert native.load_library().bfpq_tune(2, v) == 0
             g = native.hbfp_linear_mx8(x, w8, wsc, 3, out_dtype=torch.float32)
             ref = g if ref is None else ref

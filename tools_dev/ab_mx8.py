@@ -11,7 +11,7 @@ from quantization_sparsity_interplay_amd.bfp import bfp_ops
 L = native.load_library()
 dev = "cuda:0"
 variants = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 3, 4, 5]
-shapes = [(2048, 4096, 4096), (2048, 4096, 11008), (2048, 11008, 4096), (8192, 4096, 11008), (512, 4096, 11008), (2048, 5120, 13824)]
+shapes = [(int(a) for a in sh.split('x')) for sh in os.environ['SHAPES'].split(',')] if os.environ.get('SHAPES') else [(2048, 4096, 4096), (2048, 4096, 11008), (2048, 11008, 4096), (8192, 4096, 11008), (512, 4096, 11008), (2048, 5120, 13824)]
 for T, K, N in shapes:
     x = (torch.randn(T, K, device=dev)).to(torch.bfloat16)
     w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
