@@ -95,6 +95,21 @@ def main():
             g_ref = time_graph(lambda: ref(x), 50)
         rows.append(dict(case=name, graph_us=g_lin, eager_us=e_lin, issue_us=i_lin, flinear_graph_us=g_ref, flinear_eager_us=e_ref))
         print(f"{name:48s} graph {g_lin:7.2f} (F.linear {g_ref:6.2f}) | eager {e_lin:7.2f} (host issue {i_lin:6.2f}) | F.linear eager {e_ref:6.2f}", flush=True)
+    # prefill from the packed weight / the cached module on the matrix unit: activation image + matrix kernel per call
+    native.SHARE_ACT_IMAGE = False
+    for name, fin, fout, tokens in (("PackedBFP.linear q_proj 2048 tokens", 4096, 4096, 2048), ("PackedBFP.linear gate_proj 2048 tokens", 4096, 11008, 2048),
+                                    ("PackedBFP.linear gate_proj 256 tokens", 4096, 11008, 256)):
+        w = (torch.randn(fout, fin, device=DEV) * 0.02).to(torch.bfloat16)
+        x = torch.randn(tokens, fin, device=DEV, dtype=torch.bfloat16)
+        pw = bfp_ops.PackedBFP.quantize(w, 3, 64, N=2, M=4)
+        lin = bfp_ops.BFPLinear(fin, fout, bias=False, **cfg(device="cuda")).to(DEV).to(torch.bfloat16).eval().enable_weight_cache(matrix_unit=True)
+        with torch.no_grad():
+            e_p, i_p = time_eager(lambda: pw.linear(x, x_mant_bits=3), args.n)
+            g_p = time_graph(lambda: pw.linear(x, x_mant_bits=3), 20)
+            e_m, i_m = time_eager(lambda: lin(x), args.n)
+            e_ref, i_ref = time_eager(lambda: torch.nn.functional.linear(x, w), args.n)
+        rows.append(dict(case=name, graph_us=g_p, eager_us=e_p, issue_us=i_p, module_eager_us=e_m, module_issue_us=i_m, flinear_eager_us=e_ref))
+        print(f"{name:48s} graph {g_p:7.2f} | eager {e_p:7.2f} (host issue {i_p:6.2f}) | BFPLinear matrix unit eager {e_m:7.2f} (host issue {i_m:6.2f}) | F.linear eager {e_ref:6.2f}", flush=True)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(rows, open(args.out, "w"), indent=1)
 
