@@ -246,6 +246,14 @@ int bfpq_hbfp_linear_mx8_ok(int64_t T, int64_t N, int64_t K);   /* 1 when the ke
 int bfpq_hbfp_linear_mx8(const void* x8_dev, const void* xscale_dev, const void* w8_dev, const void* wscale_dev, const void* bias_dev,
                          void* out_dev, int64_t T, int64_t N, int64_t K, int out_dtype, void* stream);
 
+/* short token counts (<= 256) leave too few output tiles for the chip (128 tokens x [4096 x 11008]: 32 tiles): K is then split over
+ * `parts` workgroups per tile, each writing an fp32 slab, added in part order (deterministic) by a second small launch.
+ * bfpq_hbfp_linear_mx8_parts: the number of parts the plan wants for this shape (1: use bfpq_hbfp_linear_mx8);
+ * slabs_dev: parts * T * N floats, 16-byte aligned. */
+int bfpq_hbfp_linear_mx8_parts(int64_t T, int64_t N, int64_t K);
+int bfpq_hbfp_linear_mx8_splitk(const void* x8_dev, const void* xscale_dev, const void* w8_dev, const void* wscale_dev, const void* bias_dev,
+                                void* out_dev, float* slabs_dev, int parts, int64_t T, int64_t N, int64_t K, int out_dtype, void* stream);
+
 /* the first BFPQ_SELECT_STATE_BYTES of ws_dev, as read back by a host that wants tau / counts (little-endian) */
 typedef struct bfpq_select_state {
     uint32_t prefix;      /* magnitude bits decided so far (high digits)                         */

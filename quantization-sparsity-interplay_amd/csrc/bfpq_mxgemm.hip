@@ -286,7 +286,7 @@ template <int OUT_DT, int WM, int WN, int TM, int TN, int KB, int NS>
 __device__ __forceinline__ void ring_tile(uint8_t* lds, int orig, int nwg, int n_base,
                                           const uint8_t* __restrict__ x8, const uint8_t* __restrict__ xs, const uint8_t* __restrict__ w8,
                                           const uint8_t* __restrict__ wsc, const void* __restrict__ bias, void* __restrict__ out,
-                                          int T, int N, int K, int tiles_t)
+                                          int T, int N, int K, int tiles_t, int tr0 = 0, int tr1 = -1)
 {
     using C = RingCfg<WM, WN, TM, TN, KB, NS>;
     constexpr int NW = C::NW, NT = C::NT, BM = C::BM, BN = C::BN, STAGE = C::STAGE;
@@ -302,7 +302,9 @@ __device__ __forceinline__ void ring_tile(uint8_t* lds, int orig, int nwg, int n
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     const int t0 = (wg % tiles_t) * BM, n0 = n_base + (wg / tiles_t) * BN;
-    const int nb = K >> 6, S = nb / KB, trips = nb >> 2;
+    const int nb = K >> 6;
+    const int trips = tr1 < 0 ? nb >> 2 : tr1;                                  // this workgroup's trips of K: [tr0, trips) (all of K unless K is split)
+    const int S = trips * (4 / KB);                                            // one past its last stage
 
     auto swz = [](int row) { return KB == 1 ? (row >> 2) & 3 : (row >> 1) & 7; };
     size_t offA[GA], offB[GB];
@@ -384,14 +386,14 @@ __device__ __forceinline__ void ring_tile(uint8_t* lds, int orig, int nwg, int n
         slot = slot + 1 == NS ? 0 : slot + 1;
     };
 
-    // prologue: scales of trip 0 and stages 0 .. D-1, drained once
-    stage_scales(0);
+    // prologue: scales of the first trip and its stages 0 .. D-1, drained once
+    stage_scales(tr0);
 #pragma unroll
-    for (int d = 0; d < D; d++) stage(d, d);
+    for (int d = 0; d < D; d++) stage(tr0 * SPT + d, d);
     wait_vm<0>();
     __builtin_amdgcn_s_barrier();
     int slot = 0;
-    for (int tr = 0; tr < trips; tr++) {
+    for (int tr = tr0; tr < trips; tr++) {
         const int s = tr * SPT;
         const int trn = tr + 1 < trips ? tr + 1 : tr;
         const uint32_t* const sc = reinterpret_cast<const uint32_t*>(sscale + (tr & 1) * NT * 4);
@@ -462,6 +464,32 @@ __global__ void __launch_bounds__(64 * WM * WN) k_mx8_gemm_ring(const uint8_t* _
     ring_tile<OUT_DT, WM, WN, TM, TN, KB, NS>(lds, (int)blockIdx.x, (int)gridDim.x, 0, x8, xs, w8, wsc, bias, out, T, N, K, tiles_t);
 }
 
+// K split over `splits` workgroups per output tile (short token counts: too few tiles for the chip, e.g. 128 tokens x down_proj = 32 tiles
+// over K = 11008): workgroup (tile, part) accumulates its trips of K into the fp32 slab `part`; k_mx8_splitk_reduce adds the slabs in part
+// order (deterministic), the bias, and rounds to the output dtype.
+template <int WM, int WN, int TM, int TN, int KB, int NS>
+__global__ void __launch_bounds__(64 * WM * WN) k_mx8_gemm_ring_splitk(const uint8_t* __restrict__ x8, const uint8_t* __restrict__ xs, const uint8_t* __restrict__ w8,
+                                                                       const uint8_t* __restrict__ wsc, float* __restrict__ slabs,
+                                                                       int T, int N, int K, int tiles_t, int tiles, int trips_per_part)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t lds[RingCfg<WM, WN, TM, TN, KB, NS>::LDS_BYTES];
+    const int part = (int)blockIdx.x / tiles, tile = (int)blockIdx.x % tiles;
+    const int trips = K >> 8, a = part * trips_per_part, b = a + trips_per_part < trips ? a + trips_per_part : trips;
+    ring_tile<BFPQ_F32, WM, WN, TM, TN, KB, NS>(lds, tile, tiles, 0, x8, xs, w8, wsc, nullptr, slabs + (size_t)part * T * N, T, N, K, tiles_t, a, b);
+}
+
+template <int OUT_DT>
+__global__ void __launch_bounds__(256) k_mx8_splitk_reduce(const float* __restrict__ slabs, const void* __restrict__ bias, void* __restrict__ out, int64_t TN_, int N, int parts)
+{
+    using raw_t = typename Traits<OUT_DT>::raw_t;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < TN_; i += (int64_t)gridDim.x * 256) {
+        float acc = slabs[i];
+        for (int p = 1; p < parts; p++) acc += slabs[(size_t)p * TN_ + i];
+        if (bias) acc += raw_to_f32<OUT_DT>((uint32_t)reinterpret_cast<const raw_t*>(bias)[i % N]);
+        reinterpret_cast<raw_t*>(out)[i] = (raw_t)f32_to_raw<OUT_DT>(acc);
+    }
+}
+
 // Two tile shapes in one launch.  256 x 256 tiles need half the operand bytes per flop, but N / 256 x T / 256 of them rarely fill
 // the 256 CUs a whole number of times (2048 tokens x 11008 features: 344 tiles = one full round and a third of a second one).  So
 // the first n_big workgroups (whole rounds of the chip) take 256 x 256 tiles of the first columns, the remaining columns go in
@@ -488,7 +516,7 @@ __global__ void __launch_bounds__(512) k_mx8_gemm_ring_mixed(const uint8_t* __re
 //   4: 256 x 128, 8 waves, ring of three stages of 128 B of K                                        95 / 487 / 38 /  86
 //   5: 3 for whole rounds of the chip + 4 for the remaining columns, one launch                      90 / 389 / 37 /  86   (default otherwise)
 //   6: 128 x 128, 4 waves, ring of three stages of 128 B of K (default up to 256 tokens: 128 tokens x gate_proj 23 us, variant 0: 39, variant 4: 30;
-//      128 tokens x down_proj -- 32 tiles, K = 11008 -- 50 us: a split of K is what that shape wants)
+//      128 tokens x down_proj -- 32 tiles, K = 11008 -- 50 us unsplit, 22 us with K split over 8 workgroups per tile: bfpq_hbfp_linear_mx8_splitk)
 //   (the ring's epilogue through a wave-private LDS patch, 16-byte stores: +1-3 % over lane-by-lane 2-byte stores; s_setprio(1) around the matrix
 //    instructions of a stage: -5...15 %, removed; a 256 x 128 ring with 64-byte stages -- four matrix instructions per barrier -- ran 113 / 515 / 45 / 106; 256 x 128 and 128 x 256 in the
 //    two-stage form 10-25 % behind variant 0; weight fragments loaded straight into registers, 32 rows x 64 B per load instruction, 1.5x slower: removed)
@@ -580,6 +608,45 @@ int bfpq_hbfp_linear_mx8(const void* x8, const void* xs, const void* w8, const v
     if (out_dtype == BFPQ_F32) return launch_mx8<BFPQ_F32>(variant, a, as, b, bs, bias, out, (int)T, (int)N, (int)K, s);
     if (out_dtype == BFPQ_F16) return launch_mx8<BFPQ_F16>(variant, a, as, b, bs, bias, out, (int)T, (int)N, (int)K, s);
     return launch_mx8<BFPQ_BF16>(variant, a, as, b, bs, bias, out, (int)T, (int)N, (int)K, s);
+}
+
+/* K split for short token counts: how many parts the plan wants (1: call bfpq_hbfp_linear_mx8), and the call that takes the
+ * fp32 slabs [parts, T, N] */
+int bfpq_hbfp_linear_mx8_parts(int64_t T, int64_t N, int64_t K)
+{
+    if (!bfpq_hbfp_linear_mx8_ok(T, N, K) || T > 256 || (bfpq_g_mx8_variant >= 0 && bfpq_g_mx8_variant != 6)) return 1;
+    const int64_t tiles = ((T + 127) / 128) * ((N + 127) / 128), trips = K / 256;
+    if (tiles >= 128 || trips < 4) return 1;
+    int64_t parts = 256 / tiles;
+    if (parts > 8) parts = 8;
+    if (parts > trips / 2) parts = trips / 2;                                   // at least two trips per part
+    return parts < 2 ? 1 : (int)parts;
+}
+
+int bfpq_hbfp_linear_mx8_splitk(const void* x8, const void* xs, const void* w8, const void* ws, const void* bias, void* out, float* slabs, int parts,
+                                int64_t T, int64_t N, int64_t K, int out_dtype, void* stream)
+{
+    if (out_dtype < 0 || out_dtype > 2 || T < 0 || N < 0 || parts < 1 || parts > 64) return BFPQ_E_ARG;
+    if (T == 0 || N == 0) return 0;
+    if (!bfpq_hbfp_linear_mx8_ok(T, N, K)) return BFPQ_E_UNSUPPORTED;
+    if (!x8 || !xs || !w8 || !ws || !out || !slabs) return BFPQ_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(x8) | reinterpret_cast<uintptr_t>(w8) | reinterpret_cast<uintptr_t>(slabs)) & 15u) return BFPQ_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(xs) | reinterpret_cast<uintptr_t>(ws)) & 3u) return BFPQ_E_ARG;
+    const int trips = (int)(K / 256);
+    if (parts > trips) parts = trips;
+    const int tpp = (trips + parts - 1) / parts;
+    parts = (trips + tpp - 1) / tpp;                                            // (no empty part)
+    const int tiles_t = (int)((T + 127) / 128), tiles = tiles_t * (int)((N + 127) / 128);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((k_mx8_gemm_ring_splitk<2, 2, 2, 2, 2, 3>), dim3((unsigned)(tiles * parts)), dim3(256), 0, s, (const uint8_t*)x8, (const uint8_t*)xs,
+                       (const uint8_t*)w8, (const uint8_t*)ws, slabs, (int)T, (int)N, (int)K, tiles_t, tiles, tpp);
+    const int64_t tn = T * N;
+    int64_t g = (tn + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (out_dtype == BFPQ_F32) hipLaunchKernelGGL((k_mx8_splitk_reduce<BFPQ_F32>), dim3((unsigned)g), dim3(256), 0, s, (const float*)slabs, bias, out, tn, (int)N, parts);
+    else if (out_dtype == BFPQ_F16) hipLaunchKernelGGL((k_mx8_splitk_reduce<BFPQ_F16>), dim3((unsigned)g), dim3(256), 0, s, (const float*)slabs, bias, out, tn, (int)N, parts);
+    else hipLaunchKernelGGL((k_mx8_splitk_reduce<BFPQ_BF16>), dim3((unsigned)g), dim3(256), 0, s, (const float*)slabs, bias, out, tn, (int)N, parts);
+    return (int)hipGetLastError();
 }
 
 }  // extern "C"

@@ -98,17 +98,20 @@ def load_library():
         L.bfpq_quantize_mx8.argtypes = [vp, vp, vp, i64, i64, i32, i32, dbl, vp, vp]
         L.bfpq_hbfp_linear_mx8_ok.argtypes = [i64, i64, i64]
         L.bfpq_hbfp_linear_mx8.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]
+        L.bfpq_hbfp_linear_mx8_parts.argtypes = [i64, i64, i64]
+        L.bfpq_hbfp_linear_mx8_splitk.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, i64, i32, vp]
         for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_is_fused", "bfpq_nm_sparsify",
                      "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
                      "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize", "bfpq_hbfp_linear_slices",
                      "bfpq_hbfp_linear_decode", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled",
-                     "bfpq_mx8_from_hbfp", "bfpq_quantize_mx8", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8"):
+                     "bfpq_mx8_from_hbfp", "bfpq_quantize_mx8", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8",
+                     "bfpq_hbfp_linear_mx8_parts", "bfpq_hbfp_linear_mx8_splitk"):
             getattr(L, name).restype = i32
         _lib = L
         return _lib
 
 
-EXPORTED_SYMBOLS = ("bfpq_quantize_mx8", "bfpq_mx8_from_hbfp", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_select_ws_bytes", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24",
+EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_mx8_parts", "bfpq_hbfp_linear_mx8_splitk", "bfpq_quantize_mx8", "bfpq_mx8_from_hbfp", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_select_ws_bytes", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_is_fused", "bfpq_nm_sparsify",
                     "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
                     "bfpq_threshold_apply", "bfpq_quantize_threshold")
@@ -690,6 +693,7 @@ def quantize_mx8(x, mant_bits, epsilon=1e-8):
 
 
 _last_image = {}          # device -> (key, the tensor itself, image): q/k/v (and gate/up) of a block are called on the same tensor
+SPLIT_K = True            # False: never split K (A/B measurements)
 SHARE_ACT_IMAGE = True    # False: every call quantizes its activation (single-layer benchmarks that re-use one input tensor)
 
 
@@ -731,6 +735,12 @@ def hbfp_linear_mx8(x, w8, wscale, x_mant_bits, epsilon=1e-8, bias=None, out_dty
         out = torch.empty((T, N), dtype=out_dtype, device=dev)
         if bias is not None:
             bias = bias.to(out_dtype).contiguous()
-        check(L.bfpq_hbfp_linear_mx8(_ptr(x8), _ptr(xs), _ptr(w8), _ptr(wscale), _ptr(bias) if bias is not None else None, _ptr(out),
-                                     T, N, K, DTYPE_CODE[out_dtype], _stream(x)), "bfpq_hbfp_linear_mx8")
+        parts = L.bfpq_hbfp_linear_mx8_parts(T, N, K) if SPLIT_K else 1
+        if parts > 1:                                                  # few tokens: K split over several workgroups per tile, fp32 slabs
+            slabs = torch.empty((parts, T, N), dtype=torch.float32, device=dev)
+            check(L.bfpq_hbfp_linear_mx8_splitk(_ptr(x8), _ptr(xs), _ptr(w8), _ptr(wscale), _ptr(bias) if bias is not None else None, _ptr(out),
+                                                _ptr(slabs), parts, T, N, K, DTYPE_CODE[out_dtype], _stream(x)), "bfpq_hbfp_linear_mx8_splitk")
+        else:
+            check(L.bfpq_hbfp_linear_mx8(_ptr(x8), _ptr(xs), _ptr(w8), _ptr(wscale), _ptr(bias) if bias is not None else None, _ptr(out),
+                                         T, N, K, DTYPE_CODE[out_dtype], _stream(x)), "bfpq_hbfp_linear_mx8")
     return out.view(tuple(x.shape[:-1]) + (N,))

@@ -56,6 +56,9 @@ def test_argument_validation_without_gpu():
     assert L.bfpq_quantize_mx8(one, one, one, 4, 64, native.F32, 3, 1e-8, one, n) == -2                               # fp32: through the codes
     assert L.bfpq_quantize_mx8(one, one, one, 4, 64, native.BF16, 5, 1e-8, one, n) == -1
     assert L.bfpq_quantize_mx8(one, one, one, 0, 64, native.BF16, 3, 1e-8, one, n) == 0
+    assert L.bfpq_hbfp_linear_mx8_parts(128, 4096, 11008) == 8 and L.bfpq_hbfp_linear_mx8_parts(2048, 4096, 11008) == 1 and L.bfpq_hbfp_linear_mx8_parts(128, 11008, 4096) == 2
+    assert L.bfpq_hbfp_linear_mx8_splitk(one, one, one, one, n, one, n, 4, 8, 8, 256, native.BF16, n) == -1           # no slabs
+    assert L.bfpq_hbfp_linear_mx8_splitk(one, one, one, one, n, one, one, 0, 8, 8, 256, native.BF16, n) == -1         # parts < 1
     assert L.bfpq_tune(2, 7) == -1 and L.bfpq_tune(2, 6) == 0 and L.bfpq_tune(2, -1) == 0
     assert L.bfpq_hbfp_linear_decode(one, one, one, one, one, one, 17, 4096, 11008, native.BF16, 3, 7, n) == -1      # row-major layout: <= 16 tokens
     assert L.bfpq_nm8_lut_host(0, one) == -1 and L.bfpq_nm8_lut_host(4, n) == -1

@@ -825,6 +825,33 @@ def test_quantize_mx8_equals_codes_then_image(dname, xm):
     assert torch.equal(val[ok], want[ok])
 
 
+@pytest.mark.parametrize("N,K,T", [(512, 4096, 100), (256, 11008, 128), (384, 1024, 33)])
+def test_packed_consumer_prefill_split_k(N, K, T):
+    """short token counts: K split over several workgroups per output tile, fp32 slabs added in part order -- against the fp64 product,
+    equal to the unsplit kernel up to the fp32 summation order, and reproducible"""
+    dt = torch.bfloat16
+    w = synth(N, K, dt).to(DEV)
+    x = synth(T, K, dt, 1.0, seed=9).to(DEV)
+    bias = synth(1, N, dt, 1.0, seed=3).to(DEV).view(N)
+    pw = bfp_ops.PackedBFP.quantize(w, 3, 64, N=2, M=4)
+    w8, wsc = native.mx8_from_hbfp(pw.codes, pw.exps, K, 3, 4)
+    parts = native.load_library().bfpq_hbfp_linear_mx8_parts(T, N, K)
+    assert parts > 1
+    xq = bfp_ops.float_to_bfp_blocked(x, **cfg(mant_bits=3, block_size=64), identifier='in').double().cpu()
+    want = xq @ pw.dequantize().double().cpu().t() + bias.double().cpu()
+    got = native.hbfp_linear_mx8(x, w8, wsc, 3, bias=bias, out_dtype=torch.float32)
+    assert float((got.double().cpu() - want).abs().max() / want.abs().max()) < 2e-6
+    assert torch.equal(got, native.hbfp_linear_mx8(x, w8, wsc, 3, bias=bias, out_dtype=torch.float32))
+    try:
+        native.SPLIT_K = False
+        one = native.hbfp_linear_mx8(x, w8, wsc, 3, bias=bias, out_dtype=torch.float32)
+    finally:
+        native.SPLIT_K = True
+    assert float((got - one).abs().max() / want.abs().max()) < 2e-6
+    gb = native.hbfp_linear_mx8(x, w8, wsc, 3, bias=bias)                 # bf16 output through the reduce launch
+    assert gb.dtype == dt and float((gb.double().cpu() - want).abs().max() / want.abs().max()) < 6e-3
+
+
 @pytest.mark.parametrize("dname", ["bf16", "f32"])
 def test_bfplinear_cached_on_the_matrix_unit(dname):
     """opt-in enable_weight_cache(matrix_unit=True): the reference's module (bfp_ops.py:270-287) with its Linear on the block-scaled
