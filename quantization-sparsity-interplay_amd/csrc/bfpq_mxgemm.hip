@@ -580,6 +580,9 @@ int bfpq_hbfp_linear_mx8_ok(int64_t T, int64_t N, int64_t K)
            ((T + 127) / 128) * ((N + 127) / 128) < ((int64_t)1 << 30);
 }
 
+// the 128 x 128 tile (and, through bfpq_hbfp_linear_mx8_parts, a split of K) whenever the larger tiles would leave half the chip idle
+static bool mx8_short(int64_t T, int64_t N) { return T <= 256 || ((T + 255) / 256) * ((N + 127) / 128) < 128; }
+
 __attribute__((visibility("hidden"))) int bfpq_g_mx8_variant = -1;             // -1 = choose; 0..6 force (bfpq_tune, BFPQ_TUNE_MX8_VARIANT)
 
 int bfpq_hbfp_linear_mx8(const void* x8, const void* xs, const void* w8, const void* ws, const void* bias, void* out,
@@ -601,7 +604,7 @@ int bfpq_hbfp_linear_mx8(const void* x8, const void* xs, const void* w8, const v
         const int64_t n_small = big_cols * 256 < N ? (N - big_cols * 256 + 127) / 128 * tt : 0;
         const double est_big = (double)R + (tiles % 256 ? 0.72 : 0.0);
         const double est_mixed = (double)(big_cols * tt) / 256.0 + 0.60 * ((double)(n_small / 256) + (n_small % 256 ? 0.72 : 0.0));
-        variant = T <= 256 ? 6 : (est_mixed < 0.92 * est_big ? 5 : 3);
+        variant = mx8_short(T, N) ? 6 : (est_mixed < 0.92 * est_big ? 5 : 3);
     }
     hipStream_t s = (hipStream_t)stream;
     const uint8_t *a = (const uint8_t*)x8, *as = (const uint8_t*)xs, *b = (const uint8_t*)w8, *bs = (const uint8_t*)ws;
@@ -614,9 +617,9 @@ int bfpq_hbfp_linear_mx8(const void* x8, const void* xs, const void* w8, const v
  * fp32 slabs [parts, T, N] */
 int bfpq_hbfp_linear_mx8_parts(int64_t T, int64_t N, int64_t K)
 {
-    if (!bfpq_hbfp_linear_mx8_ok(T, N, K) || T > 256 || (bfpq_g_mx8_variant >= 0 && bfpq_g_mx8_variant != 6)) return 1;
+    if (!bfpq_hbfp_linear_mx8_ok(T, N, K) || !mx8_short(T, N) || (bfpq_g_mx8_variant >= 0 && bfpq_g_mx8_variant != 6)) return 1;
     const int64_t tiles = ((T + 127) / 128) * ((N + 127) / 128), trips = K / 256;
-    if (tiles >= 128 || trips < 4) return 1;
+    if (tiles > 128 || trips < 4) return 1;
     int64_t parts = 256 / tiles;
     if (parts > 8) parts = 8;
     if (parts > trips / 2) parts = trips / 2;                                   // at least two trips per part
