@@ -108,8 +108,11 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--models", action="store_true", help="also (or with --models-only: only) the whole-model passes")
     ap.add_argument("--models-only", action="store_true")
+    ap.add_argument("--tune-grid", type=int, default=0, help="A/B: cap on workgroups of the streaming kernels (bfpq_tune key 0)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    if args.tune_grid:
+        assert native.load_library().bfpq_tune(0, args.tune_grid) == 0
     results = []
     if args.models_only:
         results = model_rows(args, dev)
