@@ -861,9 +861,11 @@ int launch_fused_nm8(const FusedArgs& a, hipStream_t s)
         }
         return 0;
     }
-    // N:8 is bound by its ~150 packed comparisons per item, not by HBM: twice the workgroups of the drop-in grid keep the VALU fed while others
-    // wait for memory ([4096,11008] bf16 4:8, interleaved sweep of the cap: 1024 -> 52.0 us, 1536 -> 50.2, 2048 -> 47.7, 2752 -> 48.2)
-    const dim3 grid(grid_for_cap(a.n_items, (int64_t)kMaxGrid * 2)), block(kThreads);
+    // N:8 on a 16-bit tensor, pruned before it is quantized, is bound by its ~150 packed comparisons per item, not by HBM: twice the workgroups
+    // of the drop-in grid keep the VALU fed while others wait for memory ([4096,11008] bf16 4:8 s, sweep of the cap on one box: 1024 -> 52.0 us,
+    // 1536 -> 50.2, 2048 -> 47.7, 2752 -> 48.2).  Quantize-first inputs (every group ties at the cut and reads the 16 MiB rank table) and fp32
+    // (already at 63 % of HBM) lose 3 % with the larger grid and keep the drop-in one.
+    const dim3 grid(grid_for_cap(a.n_items, (int64_t)kMaxGrid * ((Traits<DT>::VEC == 8 && SFIRST) ? 2 : 1))), block(kThreads);
     const bool deq_only = a.out_deq && !a.out_codes && !a.out_exp;
     if constexpr (STOCH) hipLaunchKernelGGL((k_fused_flat<DT, 8, SFIRST, true, -1, false>), grid, block, 0, s, a);
     else if constexpr (Traits<DT>::VEC == 8) {

@@ -825,6 +825,35 @@ def test_quantize_mx8_equals_codes_then_image(dname, xm):
     assert torch.equal(val[ok], want[ok])
 
 
+def test_packed_consumer_prefill_random_shapes():
+    """24 random problems (tokens 1-900, features 8-1300, K a multiple of 256 up to 2304; dtypes, N:M patterns, mantissa widths, bias or
+    not) through PackedBFP.linear on the matrix unit -- whatever tile plan / K split the shape picks -- against the fp64 product of the
+    oracle-pinned fake-quantised operands"""
+    import random
+    rng = random.Random(20260)
+    for case in range(24):
+        T, N, K = rng.randint(1, 900), rng.randint(1, 160) * 8 + rng.choice([0, 0, 0, 4]), 256 * rng.randint(1, 9)
+        dname = rng.choice(["bf16", "bf16", "f16", "f32"])
+        dt = DT[dname]
+        wm, xm = rng.choice([3, 3, 2, 1]), rng.choice([3, 3, 4, 2])
+        nm = rng.choice([(0, 0), (2, 4), (1, 4), (4, 8)])
+        w = synth(N, K, dt, 0.02, seed=100 + case).to(DEV)
+        x = synth(T, K, dt, rng.choice([1.0, 0.05, 30.0]), seed=200 + case).to(DEV)
+        bias = synth(1, N, dt, 1.0, seed=300 + case).to(DEV).view(N) if rng.random() < 0.5 else None
+        pw = bfp_ops.PackedBFP.quantize(w, wm, 64, N=nm[0], M=nm[1])
+        got = pw.linear(x, bias, x_mant_bits=xm, decode_tokens=0)
+        assert got.shape == (T, N) and got.dtype == dt
+        xq = bfp_ops.float_to_bfp_blocked(x, **cfg(mant_bits=xm, block_size=64), identifier='in').double().cpu()
+        want = xq @ pw.dequantize().double().cpu().t()
+        if bias is not None:
+            want = want + bias.double().cpu()
+        nan = torch.isnan(want)
+        assert torch.equal(torch.isnan(got.cpu()), nan), (case, T, N, K, dname)
+        if bool((~nan).any()):
+            err = float((got.double().cpu() - want)[~nan].abs().max() / want[~nan].abs().max().clamp_min(1e-30))
+            assert err < {"f32": 2e-6, "bf16": 6e-3, "f16": 8e-4}[dname], (case, T, N, K, dname, wm, xm, nm, err)
+
+
 @pytest.mark.parametrize("N,K,T", [(512, 4096, 100), (256, 11008, 128), (384, 1024, 33)])
 def test_packed_consumer_prefill_split_k(N, K, T):
     """short token counts: K split over several workgroups per output tile, fp32 slabs added in part order -- against the fp64 product,
