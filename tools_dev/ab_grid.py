@@ -3,7 +3,7 @@ import ctypes, os, sys, statistics, torch
 sys.path.insert(0, '.')
 from quantization_sparsity_interplay_amd import native
 lib = native.load_library()
-rows, cols, L, R, ROUNDS = 4096, 11008, 100, 8, 9
+rows, cols, L, R, ROUNDS = 4096, 11008, 100, int(os.environ.get("ROTATE", "8")), 9
 NN, MM = 2, 4
 if len(sys.argv) >= 5:                      # usage: ab_grid.py rows cols N M
     rows, cols, NN, MM = (int(a) for a in sys.argv[1:5])
