@@ -149,15 +149,19 @@ __device__ __forceinline__ void load_vec_f(const void* in, int64_t item, float* 
     }
 }
 
+// A workgroup = 64 adjacent column groups (one wave's width: 1 KB of a row) x 4 row lanes (its 4 waves); wave w reads the rows
+// 4 blockIdx.y + w, + 4 gridDim.y, ... so that the grid moves through the tensor as a compact front.  The four waves meet in LDS and
+// leave 64 VEC x 2 atomics per workgroup (one wave-instruction = 64 consecutive columns; lane-strided atomics are an order of
+// magnitude slower, MI355X_MICROARCH.md): four times the workgroups of a 256-column-group layout for the same number of atomics.
 template <int DT>
 __global__ void __launch_bounds__(kT) k_int_cols_minmax_vec(const void* in, int64_t outer, int64_t C, int64_t rows_per_chunk, uint32_t* ws)
 {
     constexpr int VEC = Traits<DT>::VEC;
+    constexpr int W = kT / 64;
     const int64_t ipr = C / VEC;
-    const int64_t cg = (int64_t)blockIdx.x * kT + threadIdx.x;
-    // rows blockIdx.y, + gridDim.y, + 2 gridDim.y, ...: at any moment the workgroups of the grid read neighbouring rows (a compact
-    // front through the tensor, as in the flat kernels) instead of 512 row chunks spread over all of it
-    const int64_t r0 = blockIdx.y, rstep = gridDim.y;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t cg = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t r0 = (int64_t)blockIdx.y * W + w, rstep = (int64_t)gridDim.y * W;
     const int64_t r1 = cg < ipr ? outer : r0;              // idle lanes: empty range
     float mn[VEC], mx[VEC];
     bool nan[VEC];
@@ -170,24 +174,22 @@ __global__ void __launch_bounds__(kT) k_int_cols_minmax_vec(const void* in, int6
 #pragma unroll
         for (int j = 0; j < VEC; j++) { nan[j] |= v[j] != v[j]; mn[j] = fminf(mn[j], v[j]); mx[j] = fmaxf(mx[j], v[j]); }
     }
-    // transpose through LDS so that one atomic wave-instruction covers 64 consecutive columns (256 contiguous
-    // bytes): lane-strided atomics are an order of magnitude slower (MI355X_MICROARCH.md, global atomics)
-    __shared__ uint32_t s_mn[kT * VEC], s_mx[kT * VEC];
+    __shared__ uint32_t s_mn[W][64 * VEC], s_mx[W][64 * VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
         if (nan[j]) { mn[j] = u2f(0xffc00000u); mx[j] = u2f(0x7fc00000u); }
-        s_mn[threadIdx.x * VEC + j] = f_key(mn[j]);
-        s_mx[threadIdx.x * VEC + j] = f_key(mx[j]);
+        s_mn[w][lane * VEC + j] = f_key(mn[j]);
+        s_mx[w][lane * VEC + j] = ~f_key(mx[j]);            // (max keys inverted: one atomicMin serves both arrays)
     }
     __syncthreads();
-    const int64_t col0 = (int64_t)blockIdx.x * kT * VEC;
+    const int64_t col0 = (int64_t)blockIdx.x * 64 * VEC;
+    for (int i = threadIdx.x; i < 2 * 64 * VEC; i += kT) {  // 64 VEC minima, then 64 VEC (inverted) maxima: consecutive columns per wave-instruction
+        const int which = i / (64 * VEC), c = i % (64 * VEC);
+        const uint32_t(*src)[64 * VEC] = which ? s_mx : s_mn;
+        uint32_t k = src[0][c];
 #pragma unroll
-    for (int j = 0; j < VEC; j++) {
-        const int64_t col = col0 + j * kT + threadIdx.x;
-        if (col < C) {
-            atomicMin(&ws[col], s_mn[j * kT + threadIdx.x]);
-            atomicMin(&ws[C + col], ~s_mx[j * kT + threadIdx.x]);
-        }
+        for (int q = 1; q < W; q++) k = k < src[q][c] ? k : src[q][c];
+        if (col0 + c < C) atomicMin(&ws[(which ? C : 0) + col0 + c], k);
     }
 }
 
@@ -462,19 +464,18 @@ int run_int(const void* in, float* out, int64_t outer, int64_t C, int64_t inner,
     if (inner == 1 && C % Traits<DT>::VEC == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0) {
         const int64_t ipr = C / Traits<DT>::VEC;
         const int64_t gx = (ipr + kT - 1) / kT;
-        auto chunking = [&](int64_t min_rows, int64_t target_wgs, int64_t* rpc_out) {
-            int64_t chunks = target_wgs / gx;
-            if (chunks < 1) chunks = 1;
-            if (chunks > (outer + min_rows - 1) / min_rows) chunks = (outer + min_rows - 1) / min_rows;
-            if (chunks > 65535) chunks = 65535;
-            *rpc_out = (outer + chunks - 1) / chunks;
-            return (unsigned)((outer + *rpc_out - 1) / *rpc_out);
-        };
-        // min/max: every thread ends with 2*VEC atomics, so give it at least 32 rows; quantize: per-thread scale set-up, 16 rows
         int64_t rpc_mm, rpc_q;
-        const unsigned gy_mm = chunking(32, 1024, &rpc_mm);             // (16 rows per thread = twice the workgroups and twice the atomics: 11.6 vs 10.4 us on [4096,4096])
+        rpc_mm = 0;
         rpc_q = 16;                                                    // the quantize launch: one batch of 16 rows per thread
-        hipLaunchKernelGGL((k_int_cols_minmax_vec<DT>), dim3((unsigned)gx, gy_mm), dim3(kT), 0, s, in, outer, C, rpc_mm, ws);
+        {
+            // 64 column groups per workgroup; every wave ~16 rows: half the atomics of the old layout at twice its workgroups
+            const int64_t gxm = (ipr + 63) / 64;
+            int64_t gym = (outer + 4 * 16 - 1) / (4 * 16);
+            if (gym * gxm > 2048) gym = (2048 + gxm - 1) / gxm;
+            if (gym < 1) gym = 1;
+            if (gym > 65535) gym = 65535;
+            hipLaunchKernelGGL((k_int_cols_minmax_vec<DT>), dim3((unsigned)gxm, (unsigned)gym), dim3(kT), 0, s, in, outer, C, rpc_mm, ws);
+        }
         const int64_t rows_per_launch = rpc_q * 65535;                 // (grid.y limit: more than a million rows go in several launches)
         for (int64_t row0 = 0; row0 < outer; row0 += rows_per_launch) {
             const int64_t n = outer - row0 < rows_per_launch ? outer - row0 : rows_per_launch;
