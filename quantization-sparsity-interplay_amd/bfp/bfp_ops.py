@@ -359,7 +359,7 @@ class PackedBFP:
         if T <= decode_tokens and self.code_bits == 4 and self.block_size == 64 and self.shape[0] % 16 == 0 and K % 256 == 0:
             out = self.linear_decode(x2, x_mant_bits, epsilon) if (T <= 16 or self._tiled_ok()) else \
                 torch.cat([self.linear_decode(x2[i:i + 16], x_mant_bits, epsilon) for i in range(0, T, 16)], 0)
-        elif self.code_bits == 4 and native.hbfp_linear_mx8_ok(T, self.shape[0], K, self.mant_bits, x_mant_bits, self.block_size):
+        elif self.code_bits in (4, 8) and native.hbfp_linear_mx8_ok(T, self.shape[0], K, self.mant_bits, x_mant_bits, self.block_size):
             # prefill: both operands as e4m3 mantissas + E8M0 block scales on the block-scaled matrix instruction
             # (exact block dot products, fp32 across blocks); the weight's image is made once per device
             out = native.hbfp_linear_mx8(x2, *self._mx8_image(), x_mant_bits, epsilon, bias=bias)
@@ -373,7 +373,7 @@ class PackedBFP:
 
     def _mx8_image(self):
         if getattr(self, "_mx8", None) is None or self._mx8[0].device != self.codes.device:
-            self._mx8 = native.mx8_from_hbfp(self.codes, self.exps, self.shape[-1], self.mant_bits, 4)
+            self._mx8 = native.mx8_from_hbfp(self.codes, self.exps, self.shape[-1], self.mant_bits, self.code_bits)
         return self._mx8
 
     def save(self, path, compact24=False):
@@ -498,8 +498,9 @@ class WeightCache:
         if self.image_key != key:
             a = bfp_args
             sp = a['w_sparsity'] == True  # noqa: E712
-            codes, exps = float_to_bfp_packed(w.detach(), a['mant_bits'], 64, a['epsilon'], a['N'] if sp else 0, a['M'] if sp else 0, a['first'], 4)
-            self.image = native.mx8_from_hbfp(codes, exps, w.shape[-1], a['mant_bits'], 4)
+            cb = 4 if a['mant_bits'] <= 3 else 8
+            codes, exps = float_to_bfp_packed(w.detach(), a['mant_bits'], 64, a['epsilon'], a['N'] if sp else 0, a['M'] if sp else 0, a['first'], cb)
+            self.image = native.mx8_from_hbfp(codes, exps, w.shape[-1], a['mant_bits'], cb)
             self.image_key = key
         return self.image
 
@@ -570,9 +571,9 @@ class _GradQuantizer(torch.autograd.Function):
 
 
 def _matrix_unit_ok(x, w, a, cache):
-    """the cached Linear forward can run on the block-scaled matrix instruction: HBFP with block 64 and <= 3 mantissa bits (4-bit codes),
+    """the cached Linear forward can run on the block-scaled matrix instruction: HBFP with block 64 and <= 4 mantissa bits (exact in e4m3),
     round-half-even, dense activations, dense or N:M weights, a 2-D weight with K % 256 == 0, enough tokens to fill a tile row"""
-    if (a['num_format'] != 'bfp' or a['sparsity_num_format'] != 'bfp' or a['block_size'] != 64 or not (1 <= a['mant_bits'] <= 3)
+    if (a['num_format'] != 'bfp' or a['sparsity_num_format'] != 'bfp' or a['block_size'] != 64 or not (1 <= a['mant_bits'] <= 4)
             or a['rounding_mode'] != rounding_modes.DETERM or a['in_sparsity'] == True or w.dim() != 2 or x.device.type != 'cuda'  # noqa: E712
             or torch.compiler.is_compiling() or not cache.usable(w, a)):
         return False

@@ -835,7 +835,7 @@ def test_packed_consumer_prefill_random_shapes():
         T, N, K = rng.randint(1, 900), rng.randint(1, 160) * 8 + rng.choice([0, 0, 0, 4]), 256 * rng.randint(1, 9)
         dname = rng.choice(["bf16", "bf16", "f16", "f32"])
         dt = DT[dname]
-        wm, xm = rng.choice([3, 3, 2, 1]), rng.choice([3, 3, 4, 2])
+        wm, xm = rng.choice([3, 3, 2, 1, 4]), rng.choice([3, 3, 4, 2])
         nm = rng.choice([(0, 0), (2, 4), (1, 4), (4, 8)])
         w = synth(N, K, dt, 0.02, seed=100 + case).to(DEV)
         x = synth(T, K, dt, rng.choice([1.0, 0.05, 30.0]), seed=200 + case).to(DEV)
@@ -918,6 +918,15 @@ def test_bfplinear_cached_on_the_matrix_unit(dname):
     with torch.no_grad():
         lin8(x)
     assert lin8.linear_op.weight_cache.mx_calls == 0                      # HBFP8 does not fit e4m3: ordinary route
+    c5 = cfg(mant_bits=4, block_size=64)                                  # HBFP5 (|mantissa| <= 15, int8 codes) still fits e4m3
+    lin5 = bfp_ops.BFPLinear(512, 384, False, **dict(c5)).to(DEV).to(dt).eval().enable_weight_cache(matrix_unit=True)
+    with torch.no_grad():
+        lin5.weight.copy_(synth(384, 512, dt).to(DEV))
+        got5 = lin5(x)
+        want5 = (bfp_ops.float_to_bfp_blocked(x, **c5, identifier='in').double().cpu().view(-1, 512)
+                 @ bfp_ops.float_to_bfp_blocked(lin5.weight, **c5, identifier='w').double().cpu().t()).view(3, 50, 384)
+    assert lin5.linear_op.weight_cache.mx_calls == 1
+    assert float((got5.double().cpu() - want5).abs().max() / want5.abs().max()) < {"f32": 2e-6, "bf16": 6e-3}[dname]
 
 
 def test_dist_paths_with_the_native_engine_on_rccl():
