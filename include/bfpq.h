@@ -237,8 +237,8 @@ int bfpq_hbfp_linear_decode_tiled(const void* wtiles_dev, const void* wexpt_dev,
  * bias (nullable) and out of out_dtype. */
 int bfpq_mx8_from_hbfp(const void* codes_dev, const int8_t* exp_dev, void* out8_dev, void* out_scale_dev, int64_t rows, int64_t cols,
                        int code_bits, int mant_bits, void* stream);
-/* a 16-bit tensor straight to its mx8 image (dense HBFP quantize, block 64, round-half-even: the activation operand of a
- * prefill; one pass, 2 B read + 1.016 B written per element).  fp32 tensors / cols % 64 != 0 / unaligned pointers: BFPQ_E_UNSUPPORTED
+/* a tensor straight to its mx8 image (dense HBFP quantize, block 64, round-half-even: the activation operand of a
+ * prefill; one pass, sizeof(dtype) B read + 1.016 B written per element).  cols % 64 != 0 / unaligned pointers: BFPQ_E_UNSUPPORTED
  * (take bfpq_quantize_nm with int8 codes + bfpq_mx8_from_hbfp). */
 int bfpq_quantize_mx8(const void* in_dev, void* out8_dev, void* out_scale_dev, int64_t rows, int64_t cols, int dtype, int mant_bits,
                       double epsilon, const uint8_t* exp_win_dev, void* stream);

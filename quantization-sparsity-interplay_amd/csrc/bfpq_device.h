@@ -129,6 +129,7 @@ struct FusedArgs {
 // (no device memory, graph-capturable).  The tensors share dtype / block / mantissa width; each is a flat array of lane
 // items cut into chunks of 256 (the last chunk of a tensor is ragged), the chunks of all tensors form one index space
 // that the workgroups stride over.  flags bit 0: apply the N:M mask to this tensor (a Linear's weight) or not (its activation).
+constexpr int kCodeBitsE4M3 = 108;                 // FusedArgs.code_bits: e4m3 image bytes + E8M0 scales (internal: bfpq_quantize_mx8 on fp32 tensors)
 constexpr int kMaxBatch = 64;
 struct BatchDesc { const void* in; void* out; int64_t n_items; uint32_t chunk0; uint32_t flags; };
 struct BatchArgs { int n; uint32_t total_chunks; BatchDesc d[kMaxBatch]; };

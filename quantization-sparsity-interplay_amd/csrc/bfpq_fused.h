@@ -503,6 +503,18 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
                 uint4* dst = reinterpret_cast<uint4*>(a.out_codes) + item * (VEC / 4);
                 dst[0] = make_uint4(f[0], f[1], f[2], f[3]);
                 if constexpr (VEC == 8) dst[1] = make_uint4(f[4], f[5], f[6], f[7]);
+            } else if (a.code_bits == kCodeBitsE4M3) {                  // e4m3 image bytes (fp32 tensors; the 16-bit dtypes have the lean PACK = 8 instantiation)
+                auto b8 = [](int cc) { const uint32_t m = (uint32_t)(cc < 0 ? -cc : cc);
+                                       const uint32_t v = m >= 8 ? 0x48u + m : (m >= 4 ? 0x40u + 2u * m : (m >= 2 ? 0x38u + 4u * m : 0x38u));
+                                       return (m ? v : 0u) | (cc < 0 ? 0x80u : 0u); };
+                uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) w0 |= b8(c[j]) << (8 * j);
+                if constexpr (VEC == 8) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) w1 |= b8(c[4 + j]) << (8 * j);
+                    reinterpret_cast<uint2*>(a.out_codes)[item] = make_uint2(w0, w1);
+                } else reinterpret_cast<uint32_t*>(a.out_codes)[item] = w0;
             } else if (a.code_bits == 8) {
                 uint32_t w0 = 0, w1 = 0;
 #pragma unroll
@@ -521,8 +533,13 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
             }
         }
         if (a.out_exp && do_quant && (item % a.lpb) == 0) {
-            const int es = e_blk < -127 ? -127 : (e_blk > 127 ? 127 : e_blk);
-            a.out_exp[item / a.lpb] = nan_blk ? (int8_t)-128 : (int8_t)es;
+            if (a.code_bits == kCodeBitsE4M3) {                           // E8M0 scale of the block: 2^(e - mant_bits); NaN block -> 0xff
+                const int sc = e_blk - a.mant_bits + 127;
+                a.out_exp[item / a.lpb] = (int8_t)(nan_blk ? 0xff : (sc < 0 ? 0 : (sc > 254 ? 254 : sc)));
+            } else {
+                const int es = e_blk < -127 ? -127 : (e_blk > 127 ? 127 : e_blk);
+                a.out_exp[item / a.lpb] = nan_blk ? (int8_t)-128 : (int8_t)es;
+            }
         }
     };
 

@@ -714,18 +714,22 @@ int bfpq_quantize_mx8(const void* in, void* out8, void* out_scale, int64_t rows,
     if (dtype < 0 || dtype > 2 || rows < 0 || cols < 0 || mant_bits < 1 || mant_bits > 4) return BFPQ_E_ARG;
     if (rows * cols == 0) return 0;
     if (!in || !out8 || !out_scale || !exp_win) return BFPQ_E_ARG;
-    if (dtype == BFPQ_F32 || cols % 64 != 0) return BFPQ_E_UNSUPPORTED;                 // (callers take bfpq_quantize_nm + bfpq_mx8_from_hbfp)
+    if (cols % 64 != 0) return BFPQ_E_UNSUPPORTED;                                     // (callers take bfpq_quantize_nm + bfpq_mx8_from_hbfp)
     if ((reinterpret_cast<uintptr_t>(in) & 15u) || (reinterpret_cast<uintptr_t>(out8) & 7u) || (reinterpret_cast<uintptr_t>(out_scale) & 7u)) return BFPQ_E_UNSUPPORTED;
     const float eps_dt = h_round((float)epsilon, dtype);
     FusedArgs a;
     a.in = in; a.out_deq = nullptr; a.out_codes = out8; a.out_exp = reinterpret_cast<int8_t*>(out_scale);
-    a.n_items = rows * cols / 8;
+    a.n_items = rows * cols / dtype_vec(dtype);
     a.exp_win = exp_win; a.nm_lut = nullptr; a.seed = 0; a.eps_dt = eps_dt;
-    a.lpb = 8;
+    a.lpb = 64 / dtype_vec(dtype);
     a.mant_bits = mant_bits; a.N = 0; a.code_bits = 8;
     a.force_slow = 0;
     set_hot16(a, dtype, mant_bits, eps_dt);
     a.selws = nullptr;
+    if (dtype == BFPQ_F32) {                                                            // fp32: the general arithmetic of the fused kernel, image bytes in its store epilogue
+        a.code_bits = kCodeBitsE4M3;
+        return fused_launch(dtype, a, 0, true, (hipStream_t)stream);
+    }
     return fused_mx8(dtype, a, (hipStream_t)stream);
 }
 

@@ -670,13 +670,13 @@ def mx8_from_hbfp(codes, exps, cols, mant_bits, code_bits):
 
 def quantize_mx8(x, mant_bits, epsilon=1e-8):
     """a 2-D tensor [T, K] -> its HBFP(mant_bits + 1) block-64 image for the block-scaled matrix unit: e4m3 bytes [T, K] + E8M0
-    scales [T, K/64].  16-bit tensors in one pass (bfpq_quantize_mx8); fp32 tensors through int8 codes + mx8_from_hbfp."""
+    scales [T, K/64], in one pass (bfpq_quantize_mx8); the two-step route (int8 codes + mx8_from_hbfp) only for shapes it refuses."""
     require_device_tensor(x)
     L = load_library()
     T, K = x.shape
     dev = x.device
     with torch.cuda.device(dev):
-        if x.dtype != torch.float32 and K % 64 == 0:
+        if K % 64 == 0:
             x = x.contiguous()
             x8 = torch.empty((T, K), dtype=torch.uint8, device=dev)
             xs = torch.empty((T, K // 64), dtype=torch.uint8, device=dev)

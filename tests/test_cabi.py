@@ -53,7 +53,7 @@ def test_argument_validation_without_gpu():
     assert L.bfpq_mx8_from_hbfp(one, one, one, one, 4, 64, 4, 4, n) == -1                                             # 4-bit codes hold <= 3 mantissa bits
     assert L.bfpq_mx8_from_hbfp(one, one, one, one, 4, 64, 8, 5, n) == -1                                             # 5 mantissa bits do not fit e4m3
     assert L.bfpq_mx8_from_hbfp(one, one, one, one, 4, 100, 8, 3, n) == -1                                            # cols % 64 != 0
-    assert L.bfpq_quantize_mx8(one, one, one, 4, 64, native.F32, 3, 1e-8, one, n) == -2                               # fp32: through the codes
+    assert L.bfpq_quantize_mx8(one, one, one, 4, 100, native.F32, 3, 1e-8, one, n) == -2                              # cols % 64 != 0: through the codes
     assert L.bfpq_quantize_mx8(one, one, one, 4, 64, native.BF16, 5, 1e-8, one, n) == -1
     assert L.bfpq_quantize_mx8(one, one, one, 0, 64, native.BF16, 3, 1e-8, one, n) == 0
     assert L.bfpq_hbfp_linear_mx8_parts(128, 4096, 11008) == 8 and L.bfpq_hbfp_linear_mx8_parts(2048, 4096, 11008) == 1 and L.bfpq_hbfp_linear_mx8_parts(128, 11008, 4096) == 2
