@@ -10,7 +10,7 @@
 // on the fake-quantised tensors (bfp_ops.py:187-190); the two agree up to fp32 summation order across blocks.
 //
 // Operand images ("mx8"): e4m3 bytes [rows, K] row-major + E8M0 scale bytes [rows, K/64], made from the packed codes and
-// exponents by k_mx8_from_codes (weights: once; activations: per call, 1 byte per element).
+// exponents by k_mx8_from_codes (weights: once); activations get theirs in one pass from the tensor (bfpq_quantize_mx8).
 //
 // Lane maps of the instruction, measured with one-hot operands (tools_dev/mxprobe): first operand lane l = row l&31 of D,
 // second operand lane l = column l&31; byte j of lane l of the first operand meets byte j of lane l of the second (so any k
@@ -18,11 +18,13 @@
 // from lane row), bytes 16-31 the second (scale taken from lane row+32) -- with one HBFP block per instruction every lane simply
 // supplies its row's scale.  D: column = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 //
-// Structure (default variant): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 = 2x2 instruction tiles each), K step of
-// 128 bytes staged global -> LDS by 16-byte LDS-DMA (global_load_lds_dwordx4), LDS rows of 128 bytes with the 16-byte slot
-// XOR-swizzled by ((row >> 1) & 7) on the source address and on the read (conflict-free ds_read_b128), 32 KB of LDS and ~128 VGPRs so
-// that several workgroups per CU overlap each other's staging.  Workgroup ids are remapped so that the workgroups of one XCD
-// walk the token tiles of the same weight tile (the weight tile is fetched into that XCD's L2 once).
+// Two kernel forms live here.  k_mx8_gemm is the first one (kept as A/B variants 0-2): 128x128 output tile per 256-thread
+// workgroup (4 waves as 2x2, 2x2 instruction tiles each), K step of 128 bytes staged global -> LDS by 16-byte LDS-DMA
+// (global_load_lds_dwordx4), LDS rows of 128 bytes with the 16-byte slot XOR-swizzled by ((row >> 1) & 7) on the source address and
+// on the read (conflict-free ds_read_b128), one or two LDS stages with a full drain at every hand-over.  ring_tile (further down) is
+// what runs by default: larger tiles, a ring of 3-4 LDS stages with counted waits and raw barriers, two tile shapes in one launch,
+// a split of K for short token counts.  In both, workgroup ids are remapped so that the workgroups of one XCD walk the token tiles
+// of the same weight tile (the weight tile is fetched into that XCD's L2 once).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "bfpq.h"
