@@ -51,7 +51,7 @@ def main():
     m = copy.deepcopy(base); patch_linear_layers(m, args, cache_weights=True, matrix_unit=True); models["BFPLinear + weight cache + matrix unit"] = m.to("cuda:0")
     m = copy.deepcopy(base).to("cuda:0"); pack_linear_layers(m, args); models["PackedBFPLinear (4-bit weights)"] = m
     rows = []
-    for tokens, iters in ((1, 20), (16, 20), (2048, 3)):
+    for tokens, iters in ((1, 20), (16, 20), (128, 20), (2048, 3)):
         ids = torch.randint(0, 1024, (1, tokens), generator=torch.Generator().manual_seed(1)).to("cuda:0")
         for name, model in models.items():
             with torch.no_grad():
