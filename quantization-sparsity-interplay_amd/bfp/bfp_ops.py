@@ -316,6 +316,23 @@ class PackedBFP:
         codes, exps = float_to_bfp_packed(t, mant_bits, block_size, epsilon, N, M, first, code_bits)
         return cls(codes, exps, t.shape, t.dtype, mant_bits, block_size, code_bits)
 
+    @classmethod
+    def quantize_unstructured(cls, t, mant_bits, block_size, sparsity_frac, epsilon=1e-8, code_bits=None):
+        """packed Q(S_unstructured(t)) -- global magnitude pruning of int(numel * frac) elements, then HBFP (the reference's
+        float_to_bfp_blocked with sparsity_mode 'unstructured', first 's': bfp_ops.py:61-71, 141-144) -- in the three launches of the
+        unstructured path, the last one writing codes + exponents instead of the tensor"""
+        native.require_device_tensor(t)
+        if code_bits is None:
+            code_bits = 4 if mant_bits <= 3 else (8 if mant_bits <= 7 else 16)
+        assert sparsity_frac > 0
+        k = int(t.numel() * sparsity_frac)
+        if k > t.numel():
+            raise RuntimeError("selected index k out of range")
+        ws = _workspace(t.device)
+        native.select_threshold(t, k, ws)
+        _, codes, exps = native.quantize_threshold(t, ws, block_size, mant_bits, epsilon, want_deq=False, code_bits=code_bits, want_exp=True)
+        return cls(codes, exps, t.shape, t.dtype, mant_bits, block_size, code_bits)
+
     def dequantize(self, out=None):
         """== the reference's fake-quantised tensor (a -0.0 there is +0.0 here)"""
         cols = self.shape[-1] if len(self.shape) else 1
@@ -499,7 +516,11 @@ class WeightCache:
             a = bfp_args
             sp = a['w_sparsity'] == True  # noqa: E712
             cb = 4 if a['mant_bits'] <= 3 else 8
-            codes, exps = float_to_bfp_packed(w.detach(), a['mant_bits'], 64, a['epsilon'], a['N'] if sp else 0, a['M'] if sp else 0, a['first'], cb)
+            if sp and a['sparsity_mode'] == 'unstructured':
+                pk = PackedBFP.quantize_unstructured(w.detach(), a['mant_bits'], 64, a['sparsity_frac'], a['epsilon'], cb)
+                codes, exps = pk.codes, pk.exps
+            else:
+                codes, exps = float_to_bfp_packed(w.detach(), a['mant_bits'], 64, a['epsilon'], a['N'] if sp else 0, a['M'] if sp else 0, a['first'], cb)
             self.image = native.mx8_from_hbfp(codes, exps, w.shape[-1], a['mant_bits'], cb)
             self.image_key = key
         return self.image
@@ -577,8 +598,12 @@ def _matrix_unit_ok(x, w, a, cache):
             or a['rounding_mode'] != rounding_modes.DETERM or a['in_sparsity'] == True or w.dim() != 2 or x.device.type != 'cuda'  # noqa: E712
             or torch.compiler.is_compiling() or not cache.usable(w, a)):
         return False
-    if a['w_sparsity'] == True and (a['sparsity_mode'] != 'structured' or not (0 < a['N'] <= a['M']) or a['M'] not in (2, 4, 8)):  # noqa: E712
-        return False
+    if a['w_sparsity'] == True:  # noqa: E712
+        if a['sparsity_mode'] == 'unstructured':
+            if a['first'] != 's' or not (0 < a['sparsity_frac'] <= 1) or w.shape[-1] % 64:       # the fused prune + quantize launch writes the codes
+                return False
+        elif a['sparsity_mode'] != 'structured' or not (0 < a['N'] <= a['M']) or a['M'] not in (2, 4, 8):
+            return False
     K = x.shape[-1]
     T = x.numel() // K if K else 0
     return T >= 32 and native.hbfp_linear_mx8_ok(T, w.shape[0], K, a['mant_bits'], a['mant_bits'], 64)

@@ -78,18 +78,24 @@ class PackedBFPLinear(torch.nn.Module):
     @classmethod
     def from_linear(cls, lin, bfp_args):
         """weight -> float_to_bfp_packed with the module's config (format 'bfp', block 64, mant_bits <= 3, round-half-even;
-        N:M from the w_sparsity keys, order from `first`); activations use mant_bits of the same config.  Configurations this
-        module cannot reproduce (unstructured weight pruning, pruned activations, stochastic rounding) are refused."""
+        N:M from the w_sparsity keys, order from `first`); activations use mant_bits of the same config.  Unstructured weight pruning is
+        packed for first='s' (prune, then quantize: one fused launch writes the codes).  Configurations this module cannot reproduce
+        (unstructured pruning after quantization, pruned activations, stochastic rounding) are refused."""
         a = bfp_ops.unpack_bfp_args(dict(bfp_args))
         assert a['num_format'] == 'bfp' and a['sparsity_num_format'] == 'bfp' and a['block_size'] == 64 and 1 <= a['mant_bits'] <= 3, \
             "PackedBFPLinear holds 4-bit codes: an HBFP config with block_size 64 and mant_bits <= 3 (HBFP4)"
-        if a['w_sparsity'] and a['sparsity_mode'] != 'structured':
-            raise ValueError("PackedBFPLinear: unstructured weight pruning is not packed here (use structured N:M, or prune the weight first)")
+        if a['w_sparsity'] and a['sparsity_mode'] == 'unstructured' and a['first'] != 's':
+            raise ValueError("PackedBFPLinear: unstructured pruning AFTER quantization (first='q') is not packed here")
+        if a['w_sparsity'] and a['sparsity_mode'] not in ('structured', 'unstructured'):
+            raise ValueError('Sparsity mode not implemented')
         if a['in_sparsity']:
             raise ValueError("PackedBFPLinear quantizes activations densely: in_sparsity is not reproduced")
         if a['rounding_mode'] != 'determ':
             raise ValueError("PackedBFPLinear packs with round-half-even: rounding_mode must be 'determ'")
         sp = a['w_sparsity'] and a['sparsity_mode'] == 'structured'
+        if a['w_sparsity'] and a['sparsity_mode'] == 'unstructured':
+            pw = bfp_ops.PackedBFP.quantize_unstructured(lin.weight.detach(), a['mant_bits'], 64, a['sparsity_frac'], a['epsilon'])
+            return cls(pw, lin.bias, a['mant_bits'], a['epsilon'])
         pw = bfp_ops.PackedBFP.quantize(lin.weight.detach(), a['mant_bits'], 64, a['epsilon'], a['N'] if sp else 0, a['M'] if sp else 0, a['first'])
         return cls(pw, lin.bias, a['mant_bits'], a['epsilon'])
 

@@ -825,6 +825,29 @@ def test_quantize_mx8_equals_codes_then_image(dname, xm):
     assert torch.equal(val[ok], want[ok])
 
 
+def test_packed_unstructured_weight_on_the_matrix_unit():
+    """cfg 4's weight form (HBFP4 + 50 % unstructured, prune then quantize) packed by the fused prune + quantize launch: the codes decode to
+    the drop-in result (pinned to the oracle's tie-class contract elsewhere), and a prefill from them equals the fp64 product"""
+    dt = torch.bfloat16
+    w = synth(384, 1024, dt).to(DEV)
+    x = synth(200, 1024, dt, 1.0, seed=9).to(DEV)
+    c = cfg(mant_bits=3, block_size=64, w_sparsity=True, sparsity_mode='unstructured', sparsity_frac=0.5, first='s')
+    pw = bfp_ops.PackedBFP.quantize_unstructured(w, 3, 64, 0.5)
+    wq = bfp_ops.float_to_bfp_blocked(w, **c, identifier='w')
+    assert torch.equal(pw.dequantize().abs(), wq.abs())                   # (a packed code has no -0)
+    assert int((wq == 0).sum()) >= w.numel() // 2
+    got = pw.linear(x, x_mant_bits=3, decode_tokens=0).double().cpu()
+    xq = bfp_ops.float_to_bfp_blocked(x, **cfg(mant_bits=3, block_size=64), identifier='in').double().cpu()
+    want = xq @ wq.double().cpu().t()
+    assert float((got - want).abs().max() / want.abs().max()) < 6e-3
+    lin = bfp_ops.BFPLinear(1024, 384, False, **dict(c)).to(DEV).to(dt).eval().enable_weight_cache(matrix_unit=True)
+    with torch.no_grad():
+        lin.weight.copy_(w)
+        got2 = lin(x).double().cpu()
+    assert lin.linear_op.weight_cache.mx_calls == 1
+    assert float((got2 - want).abs().max() / want.abs().max()) < 6e-3
+
+
 def test_packed_consumer_prefill_random_shapes():
     """24 random problems (tokens 1-900, features 8-1300, K a multiple of 256 up to 2304; dtypes, N:M patterns, mantissa widths, bias or
     not) through PackedBFP.linear on the matrix unit -- whatever tile plan / K split the shape picks -- against the fp64 product of the

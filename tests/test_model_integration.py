@@ -105,8 +105,15 @@ def test_packed_inference_model_matches_fake_quantised_model():
     tokens = torch.randint(0, 1000, (1, 12), generator=torch.Generator().manual_seed(5)).to("cuda:0")
     with torch.no_grad():
         assert torch.equal(clone(tokens).logits, packed(tokens).logits)
-    with pytest.raises(ValueError):
-        PackedBFPLinear.from_linear(torch.nn.Linear(256, 64).to("cuda:0"), dict(args, sparsity_mode='unstructured'))
+    with pytest.raises(ValueError):                                           # pruning after quantization is not packed
+        PackedBFPLinear.from_linear(torch.nn.Linear(256, 64).to("cuda:0"), dict(args, sparsity_mode='unstructured', sparsity_frac=0.5, first='q'))
+    # unstructured pruning before quantization IS: the packed module equals the BFPLinear it stands for
+    ua = dict(args, sparsity_mode='unstructured', sparsity_frac=0.5, first='s')
+    lin = torch.nn.Linear(256, 64).to("cuda:0").to(torch.bfloat16)
+    pl = PackedBFPLinear.from_linear(lin, ua)
+    from quantization_sparsity_interplay_amd.bfp import bfp_ops
+    wq = bfp_ops.float_to_bfp_blocked(lin.weight.detach(), **bfp_ops.unpack_bfp_args(dict(ua)), identifier='w')
+    assert torch.equal(pl.packed.dequantize().abs(), wq.abs()) and int((wq == 0).sum()) >= 256 * 64 // 2
 
 
 @pytest.mark.gpu
