@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--models", action="store_true", help="also (or with --models-only: only) the whole-model passes")
     ap.add_argument("--models-only", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="no hipGraph (counter collection: every dispatch is its own record)")
     ap.add_argument("--tune-grid", type=int, default=0, help="A/B: cap on workgroups of the streaming kernels (bfpq_tune key 0)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -148,6 +149,8 @@ def main():
         torch.cuda.synchronize()
         mode = "hipGraph"
         try:
+            if args.eager:
+                raise RuntimeError("--eager")
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 run()

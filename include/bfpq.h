@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BFPQ_VERSION 2
+#define BFPQ_VERSION 3
 
 enum { BFPQ_F32 = 0, BFPQ_F16 = 1, BFPQ_BF16 = 2 };
 
@@ -130,36 +130,44 @@ int bfpq_nm_sparsify(const void* in_dev, void* out_dev, int64_t rows, int64_t co
 /* ---- unstructured magnitude pruning (replaces _unstructured_sparsity, bfp_ops.py:61-71) -------
  * Exact global k-th smallest |v| by radix select on the magnitude bit pattern, then "zero everything below the
  * threshold tau and the first `need` (flat index order, lower ranks first) of the elements equal to it".
- * THREE launches for a 16-bit dtype (fp32: three histogram/resolve pairs, then the apply):
- *   for pass p in [0, bfpq_select_passes(dtype)):
- *     1. bfpq_select_hist(...)       histogram of the current digit of this device's elements; on the last pass also
- *                                    per-segment windows of it -> ws_dev
- *     2. bfpq_select_resolve(...)    picks the digit (pass 0 starts the selection with k); on the last pass leaves tau,
- *                                    need, ties and the tie bookkeeping of this device's slab in ws_dev
- *   Single device: pass hist_dev = NULL / hist_all_dev = NULL -- the launches use histogram buffers inside ws_dev, which
- *   must be ZERO before the first call; the apply launch (step 3) clears them again.  A select that is NOT followed by an
- *   apply (diagnostics) must be followed by bfpq_select_reset before the next select.
- *   Multi-GPU: give bfpq_select_hist a caller-owned hist_dev (BFPQ_SELECT_HIST_COPIES x BFPQ_SELECT_HIST_ENTRIES uint32, zero
- *   on entry), ALL-GATHER the per-rank buffers into hist_all_dev [n_ranks][BFPQ_SELECT_HIST_COPIES][BFPQ_SELECT_HIST_ENTRIES] -- the one exchange of the path: the
- *   per-rank counts of the threshold bin also tell every rank how many ties lower ranks hold -- and let
- *   bfpq_select_resolve clear the local histogram for its next use (zero_hist_dev = hist_dev).
- *   3. bfpq_threshold_apply(...) or bfpq_quantize_threshold(...)   prune (and quantize) in one pass
+ *
+ * Single device, TWO launches for a 16-bit dtype:
+ *   1. bfpq_select(...)            one launch: per-segment histograms, and the LAST workgroup to finish (an atomic ticket, no
+ *                                  workgroup ever waits for another) resolves threshold + tie bookkeeping into ws_dev.
+ *                                  fp32: three histogram/resolve launch pairs (11 + 11 + 9 bits).
+ *   2. bfpq_threshold_apply(...) or bfpq_quantize_threshold(...)   prune (and quantize) in one pass
+ * ws_dev must be ZERO before its first use; every call leaves it ready for the next one.
+ *
+ * Multi-GPU (row slabs, one global threshold): for pass p in [0, bfpq_select_passes(dtype)):
+ *     bfpq_select_hist(...)      histogram of the current digit of this device's elements into a caller-owned hist_dev
+ *                                (BFPQ_SELECT_HIST_COPIES x BFPQ_SELECT_HIST_ENTRIES uint32, zero on entry); on the last pass also
+ *                                per-segment windows of it -> ws_dev
+ *     ALL-GATHER the per-rank buffers into hist_all_dev [n_ranks][BFPQ_SELECT_HIST_COPIES][BFPQ_SELECT_HIST_ENTRIES] -- the one
+ *                                exchange of the path: the per-rank counts of the threshold bin also tell every rank how many
+ *                                ties lower ranks hold
+ *     bfpq_select_resolve(...)   picks the digit (pass 0 starts the selection with k); on the last pass leaves tau, need, ties
+ *                                and the tie bookkeeping of this device's slab in ws_dev; clears the local histogram for its
+ *                                next use (zero_hist_dev = hist_dev)
+ *   then the apply launch as above.  (hist_dev = NULL / hist_all_dev = NULL run the same launches on histogram buffers inside
+ *   ws_dev: what bfpq_select issues for fp32.)
  * ws_dev: BFPQ_SELECT_WS_BYTES bytes, zeroed once, 16-byte aligned; it begins with a bfpq_select_state.
  * k is the GLOBAL prune count int(numel_global * frac) (bfp_ops.py:66); numel_global < 2^32.
+ * in_dev and out_dev of the apply launch must not alias (the tie ranks are counted from the input while other tiles are written).
  * Tie positions: the reference's are those of a sequential introselect over the whole tensor and
  * are not reproduced; threshold, count and every element outside the tie class are.
- * How ties are ranked without a rank per tile: csrc/bfpq_kernels.hip, block comment at "Unstructured pruning". */
-#define BFPQ_SELECT_STATE_BYTES 64
+ * How ties are ranked without a rank per tile: csrc/bfpq_device.h, block comment at "Unstructured pruning". */
+#define BFPQ_SELECT_STATE_BYTES 80
 #define BFPQ_SELECT_MAX_SEGMENTS 256
 #define BFPQ_SELECT_WINDOW_BINS 2048
-#define BFPQ_SELECT_MAX_PIECES 4096
 #define BFPQ_SELECT_HIST_ENTRIES (32768 + 256)   /* fine bins, then (16-bit dtypes) 256 coarse bins of 128 */
 #define BFPQ_SELECT_HIST_COPIES 8                /* a device accumulates into 8 copies (cuts the contention of the flush) */
-#define BFPQ_SELECT_WS_BYTES (BFPQ_SELECT_STATE_BYTES + 4 * (3 * BFPQ_SELECT_HIST_COPIES * BFPQ_SELECT_HIST_ENTRIES + 2 * BFPQ_SELECT_MAX_SEGMENTS + \
-                              BFPQ_SELECT_MAX_PIECES + BFPQ_SELECT_MAX_SEGMENTS * BFPQ_SELECT_WINDOW_BINS))
+#define BFPQ_SELECT_WS_BYTES (BFPQ_SELECT_STATE_BYTES + 4 * (4 + BFPQ_SELECT_HIST_COPIES * 256 + 3 * BFPQ_SELECT_HIST_COPIES * BFPQ_SELECT_HIST_ENTRIES + \
+                              2 * BFPQ_SELECT_MAX_SEGMENTS + BFPQ_SELECT_MAX_SEGMENTS * BFPQ_SELECT_WINDOW_BINS))
 
 int bfpq_select_passes(int dtype);
 int64_t bfpq_select_ws_bytes(void);
+/* single device: every launch of the selection (16-bit dtypes: ONE) */
+int bfpq_select(const void* in_dev, int64_t numel, int dtype, int64_t k, void* ws_dev, void* stream);
 int bfpq_select_hist(const void* in_dev, int64_t numel, int dtype, int pass, int64_t k, int64_t numel_global,
                      void* ws_dev, uint32_t* hist_dev, void* stream);
 int bfpq_select_resolve(const void* in_dev, int64_t numel, int dtype, int pass, int64_t k,
@@ -263,10 +271,14 @@ typedef struct bfpq_select_state {
     uint32_t done;        /* 1 after the last pass                                               */
     int64_t need;         /* how many elements equal to tau get pruned (over all ranks)          */
     int64_t ties;         /* how many elements equal tau in total (over all ranks)               */
-    int64_t k;            /* the k given to bfpq_select_resolve                                  */
+    int64_t k;            /* the k given to the selection                                        */
     int64_t tie_base;     /* elements equal to tau held by lower ranks                           */
-    uint32_t flags;       /* bit 0: per-piece tie counts of the cut segment are valid; bit 1: the histograms inside ws_dev were used */
-    uint32_t reserved;
+    uint32_t flags;       /* bit 0: cut_* below are valid (else the apply launch derives them from the per-segment tie counts);
+                             bit 1: the fine histograms inside ws_dev were used (the apply launch clears them) */
+    uint32_t cut_lo;      /* this device's elements equal to tau go in lane items (16 B) [0, cut_lo), stay in [cut_hi, end), */
+    uint32_t cut_hi;      /* and inside [cut_lo, cut_hi) -- one segment of the histogram launch, or empty -- the first        */
+    uint32_t cut_within;  /* cut_within of them (flat order) go                                                              */
+    uint32_t reserved[2];
 } bfpq_select_state;
 
 #ifdef __cplusplus

@@ -10,6 +10,8 @@ Differences from the reference, all documented in DESIGN.md:
   * _unstructured_sparsity: which of the elements EQUAL to the threshold are pruned is "lowest flat
     index first"; the reference's choice is an artefact of a sequential introselect.
 """
+import collections
+
 import torch
 import torch.nn.functional as F
 
@@ -103,17 +105,27 @@ def _no_sparsity_float_to_bfp(t, block_size, mant_bits, epsilon, rounding_mode, 
     return _quantize_nm_ref_dtype(t, block_size, mant_bits, epsilon, rounding_mode)
 
 
-_select_ws = {}
+_select_ws = collections.OrderedDict()
+_SELECT_WS_MAX = 16                # workspaces kept (5 MB each): least recently used (device, stream) pairs beyond that are dropped
 
 
 def _workspace(device):
     """select workspace of the current stream of `device` (the launches of one call talk through it, so two streams
-    must not share one)"""
+    must not share one).  Kept per (device, stream), least recently used first out.  A workspace cannot be born inside a
+    hipGraph capture -- its zero-fill would be recorded instead of run and its memory would belong to the graph's pool -- so
+    the first unstructured call on a stream has to happen outside capture (a warm-up call, as capture needs anyway)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, torch.cuda.current_stream(idx).cuda_stream)
     ws = _select_ws.get(key)
     if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the unstructured path needs its per-stream workspace before graph capture starts: "
+                               "run the call once on this stream outside torch.cuda.graph(...) first")
         ws = _select_ws[key] = native.SelectWorkspace(torch.device("cuda", idx))
+        while len(_select_ws) > _SELECT_WS_MAX:
+            _select_ws.popitem(last=False)
+    else:
+        _select_ws.move_to_end(key)
     return ws
 
 
@@ -476,11 +488,13 @@ class WeightCache:
 
     @staticmethod
     def _key(w, bfp_args):
-        return (w.data_ptr(), w._version, w.dtype, w.device, tuple(w.shape), tuple(bfp_args.get(k) for k in _CACHE_KEYS))
+        return (w.data_ptr(), native.tensor_version(w), w.dtype, w.device, tuple(w.shape), tuple(bfp_args.get(k) for k in _CACHE_KEYS))
 
     def usable(self, w, bfp_args):
         if bfp_args.get('rounding_mode') != rounding_modes.DETERM:
             return False
+        if w.is_inference() or native.tensor_version(w) is None:
+            return False                                     # no version counter: an in-place update could not be seen
         if torch.is_grad_enabled() and w.requires_grad:
             return False
         m = self._module() if self._module is not None else None
@@ -507,6 +521,7 @@ class WeightCache:
         self.value = None
         self.image_key = None
         self.image = None
+        native.forget_shared_images()
 
     def weight_image(self, w, bfp_args):
         """e4m3 + E8M0 image of Q_w(w) for the matrix unit, made from the packed codes of the weight (not from the fake-quantised
@@ -531,6 +546,7 @@ def _pair_in_one_launch(x, w, bfp_args):
     the same plan: 'bfp' format, round-half-even, dense or structured pruning per operand; else None"""
     a = bfp_args
     if (a['sparsity_num_format'] != 'bfp' or a['rounding_mode'] != rounding_modes.DETERM or a['num_format'] != 'bfp'
+            or not a['block_size'] > 0                        # (the asserting path says what the reference says, bfp_ops.py:130)
             or x.dtype != w.dtype or x.device != w.device or x.device.type != 'cuda' or torch.compiler.is_compiling()):
         return None
     sp_in, sp_w = a['in_sparsity'] == True, a['w_sparsity'] == True  # noqa: E712

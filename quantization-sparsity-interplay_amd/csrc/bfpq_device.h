@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <string.h>
+#include <stddef.h>
 #include "bfpq.h"
 #include "bfpq_common.h"
 
@@ -189,7 +190,7 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Unstructured pruning: bookkeeping shared by the three launches (histogram, resolve, apply).
+// Unstructured pruning: bookkeeping shared by the launches (histogram [+ resolve], apply).
 //
 // Tie rule: of the elements EQUAL to the threshold, the first `need` in flat index order go (lower ranks
 // first on a row-sharded tensor) -- a pure function of the flat index, so a sharded run and a single-device
@@ -197,33 +198,36 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 //   * the histogram launch cuts the tensor into <= 256 flat-contiguous SEGMENTS, one workgroup each; the
 //     workgroup's private LDS histogram is, at the end, also an exact count of every magnitude inside the
 //     segment, and a 2048-bin WINDOW of it around the segment's own k-quantile is left in the workspace;
-//   * the resolve launch finds the threshold tau and reads every segment's tie count out of its window
-//     (a segment whose window does not cover tau and that holds magnitudes outside the window recounts
-//     itself: correct for any input, one extra read of that segment).  The cut -- the flat position where the
-//     cumulative tie count reaches `need` -- falls into one segment; that segment's ties are counted again per
-//     PIECE (<= 4096 pieces of whole 64-item tiles; one tile per piece up to 67 M items per tensor);
-//   * the apply launch (threshold_apply / the fused quantizer) turns the two small arrays into a REGION
-//     [rs, re) of lane items: every tile in front of it prunes all ties (compare against tau + 1), every tile
-//     behind it prunes none (compare against tau), and only the tiles inside it -- normally one -- rank their
-//     ties with a wave scan.
+//   * the resolve step (single device, 16-bit dtypes: the last workgroup of the histogram launch to draw its
+//     ticket; otherwise the resolve launch) finds the threshold tau and reads every segment's tie count out of
+//     its window.  The cut -- the flat position where the cumulative tie count reaches `need` -- falls into one
+//     segment: everything in front of that segment prunes all its ties (compare against tau + 1), everything
+//     behind it none (compare against tau);
+//   * the apply launch (threshold_apply / the fused quantizer) starts with kCutWGs extra workgroups that own
+//     the CUT SEGMENT: each counts the ties in front of its share of the segment's tiles (L2-resident re-reads,
+//     in parallel, nobody waits for anybody) and ranks its own tiles with a wave scan.  The ordinary
+//     workgroups do not store the tiles of the cut segment.
 // ---------------------------------------------------------------------------------------------
 constexpr int kSelThreads = 1024;
 constexpr int kMaxSeg = BFPQ_SELECT_MAX_SEGMENTS;
 constexpr int kWinBins = BFPQ_SELECT_WINDOW_BINS;
-constexpr int kMaxPieces = BFPQ_SELECT_MAX_PIECES;
 constexpr int kFineBins = 32768, kCoarseBins = 256;
+constexpr int kCutWGs = 32;                   // workgroups of the apply launch that own the cut segment (dispatched first)
 
 struct SelWs {
     bfpq_select_state st;
-    // the workspace's own histogram buffers (single-device use), one per radix pass; all zero between calls: the APPLY launch
+    uint32_t ticket;                          // fused histogram + resolve launch: workgroups that have published their segment
+    uint32_t pad_[3];
+    uint32_t coarse[BFPQ_SELECT_HIST_COPIES][kCoarseBins];   // fused launch: coarse histogram (256 bins of 128), zero between calls
+    // histogram buffers of the launch-pair path (fp32; diagnostics), one per radix pass; all zero between calls: the APPLY launch
     // clears what the histogram launches of its call dirtied (see thr_setup; bfpq_select_reset after a select with no apply)
     uint32_t hist[3][BFPQ_SELECT_HIST_COPIES][BFPQ_SELECT_HIST_ENTRIES];
-    uint32_t seg_ties[kMaxSeg];               // elements equal to tau per segment
-    uint32_t seg_win[kMaxSeg];                // first bin of the segment's window | bit 31: magnitudes outside the window exist
-    uint32_t piece_counts[kMaxPieces];        // ties per piece of the segment that holds the cut
-    uint32_t windows[kMaxSeg][kWinBins];
+    uint32_t seg_ties[kMaxSeg];               // elements equal to tau per segment (resolve launch, window-miss path)
+    uint32_t seg_win[kMaxSeg];                // first bin of the segment's window | bit 31: magnitudes outside the window exist | bit 30: 128-bin window
+    uint32_t windows[kMaxSeg][kWinBins];      // (the apply launch also dumps the ordinary workgroups' cut-segment tiles here)
 };
 static_assert(sizeof(SelWs) == BFPQ_SELECT_WS_BYTES, "bfpq.h: BFPQ_SELECT_WS_BYTES");
+static_assert(offsetof(SelWs, hist) % 16 == 0 && offsetof(SelWs, windows) % 16 == 0 && offsetof(SelWs, coarse) % 16 == 0, "SelWs: 16-byte aligned arrays");
 
 struct SegGeom { int G; int64_t L; };         // G segments of L lane items (L a multiple of 64)
 __host__ __device__ inline SegGeom seg_geom(int64_t n_items)
@@ -239,16 +243,6 @@ __host__ __device__ inline SegGeom seg_geom(int64_t n_items)
     g.G = (int)((n_items + L - 1) / L);
     if (g.G < 1) g.G = 1;
     return g;
-}
-struct PieceGeom { int n; int64_t tiles_per; };
-__host__ __device__ inline PieceGeom piece_geom(int64_t seg_len_items)
-{
-    const int64_t tiles = (seg_len_items + 63) / 64;
-    PieceGeom p;
-    p.tiles_per = (tiles + kMaxPieces - 1) / kMaxPieces;
-    if (p.tiles_per < 1) p.tiles_per = 1;
-    p.n = (int)((tiles + p.tiles_per - 1) / p.tiles_per);
-    return p;
 }
 
 // exclusive prefix sum of one value per thread over the workgroup (blockDim.x a multiple of 64, <= 1024); every thread
@@ -270,10 +264,13 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_part
 struct ThrCtx {
     uint32_t tau;
     bool on;
-    int64_t rs, re;            // the region of lane items whose ties are ranked (multiples of 64, re possibly n_items)
-    uint32_t need_in;          // ties to prune inside the region, counted from its start
-    const void* in;
-    int64_t numel;
+    int64_t cut_lo, cut_hi;    // the cut segment in lane items (multiples of 64; cut_hi possibly n_items); empty: no tile is ranked
+    uint32_t within;           // ties to prune inside the cut segment, counted from its start
+    // per tile:
+    uint32_t teff;             // ordinary workgroups: prune keys below this (tau + 1 in front of the cut segment, tau behind it)
+    bool ranked;               // cut workgroups: the ties of this tile are ranked ...
+    uint32_t before;           //   ... behind this many ties of the segment's earlier tiles
+    uint4* dump;               // where the ordinary workgroups' stores of cut-segment tiles go (never read)
 };
 
 template <int DT, bool FAST>
@@ -287,14 +284,35 @@ template <int DT> __device__ __forceinline__ uint32_t count_eq(const uint32_t* r
     return c;
 }
 
-// Region of ranked tiles for this tensor, from the workspace the resolve launch left (block-uniform result; uses
-// blockDim.x == 256 threads, >= 2 barriers).  s_part: 16 words, s_res: 8 words of LDS.
+// where the cut lies for a tensor whose per-segment tie counts are v[0..G) (one per thread, 0 beyond G): the three numbers
+// the apply launch needs.  Block-uniform result through s_res (3 words); uses block_excl_scan's barriers.
+//   need_local: ties of THIS device to prune (need - tie_base); total: this device's ties
+__device__ __forceinline__ void cut_from_seg_ties(uint32_t v, int64_t need_local, const SegGeom& g, int64_t n_items, uint32_t* s_part, uint32_t* s_res)
+{
+    uint32_t total;
+    const uint32_t excl = block_excl_scan(v, s_part, &total);
+    const int tid = threadIdx.x;
+    const uint32_t n_round = (uint32_t)((n_items + 63) / 64 * 64);
+    if (tid == 0) {
+        if (need_local <= 0) { s_res[0] = 0; s_res[1] = 0; s_res[2] = 0; }                         // no tie goes
+        else if (need_local >= (int64_t)total) { s_res[0] = n_round; s_res[1] = n_round; s_res[2] = 0; }   // every tie goes
+    }
+    if (need_local > 0 && need_local < (int64_t)total && v && (int64_t)excl <= need_local && need_local < (int64_t)excl + v) {
+        const int64_t b0 = (int64_t)tid * g.L, b1 = b0 + g.L < n_items ? b0 + g.L : n_items;
+        const uint32_t within = (uint32_t)(need_local - excl);
+        s_res[0] = (uint32_t)b0; s_res[1] = within ? (uint32_t)b1 : (uint32_t)b0; s_res[2] = within;
+    }
+    __syncthreads();
+}
+
+// Threshold + cut of this tensor for one apply workgroup, from the workspace the resolve step left (block-uniform result;
+// blockDim.x == 256 threads; barriers only on the window-miss path).  s_part: 16 words, s_res: 8 words of LDS.
 template <int DT>
-__device__ __forceinline__ void thr_setup(ThrCtx& t, SelWs* ws, const void* in, int64_t numel, int64_t n_items,
-                                          uint32_t* s_part, uint32_t* s_res)
+__device__ __forceinline__ void thr_setup(ThrCtx& t, SelWs* ws, int64_t n_items, uint32_t* s_part, uint32_t* s_res)
 {
     const bfpq_select_state* st = &ws->st;
-    if (st->flags & 2u) {
+    const uint32_t flags = st->flags;
+    if (flags & 2u) {
         // the histograms of this call have been consumed by the resolve launch: clear them for the next call
         constexpr int NC = BFPQ_SELECT_HIST_COPIES;
         const int i0 = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
@@ -307,67 +325,28 @@ __device__ __forceinline__ void thr_setup(ThrCtx& t, SelWs* ws, const void* in, 
     }
     t.tau = st->tau;
     t.on = st->k > 0;
-    t.in = in; t.numel = numel;
-    t.rs = t.re = 0; t.need_in = 0;                          // empty region at the front: no tie is pruned
+    t.cut_lo = t.cut_hi = 0; t.within = 0;                   // empty cut segment at the front: no tie is pruned
+    t.teff = 0; t.ranked = false; t.before = 0;
+    t.dump = reinterpret_cast<uint4*>(ws->windows);
     if (!t.on) { t.tau = 0; return; }                        // (k == 0: nothing is below a threshold of 0)
+    if (flags & 1u) { t.cut_lo = st->cut_lo; t.cut_hi = st->cut_hi; t.within = st->cut_within; return; }
+    // the resolve launch had to recount some segments (window miss): their tie counts are in seg_ties
     const int64_t need = st->need, ties = st->ties;
+    const uint32_t n_round = (uint32_t)((n_items + 63) / 64 * 64);
     if (need <= 0) return;
-    if (need >= ties) { t.rs = t.re = n_items; return; }    // every tie goes
+    if (need >= ties) { t.cut_lo = t.cut_hi = n_round; return; }
     const SegGeom g = seg_geom(n_items);
-    const int tid = threadIdx.x;
-    const uint32_t v = tid < g.G ? ws->seg_ties[tid] : 0u;
-    uint32_t total;
-    const uint32_t excl = block_excl_scan(v, s_part, &total);
-    int64_t local_need = need - st->tie_base;                // ties of lower ranks come first
-    if (local_need <= 0) return;
-    if (local_need >= (int64_t)total) { t.rs = t.re = n_items; return; }
-    if (v && (int64_t)excl <= local_need && local_need < (int64_t)excl + v) { s_res[0] = (uint32_t)tid; s_res[1] = (uint32_t)(local_need - excl); }
-    __syncthreads();
-    const int B = (int)s_res[0];
-    const uint32_t within = s_res[1];
-    const int64_t b0 = (int64_t)B * g.L, b1 = b0 + g.L < n_items ? b0 + g.L : n_items;
-    if (within == 0) { t.rs = t.re = b0; return; }
-    if (!(st->flags & 1u)) { t.rs = b0; t.re = b1; t.need_in = within; return; }   // no piece counts: rank the whole segment
-    const PieceGeom pg = piece_geom(b1 - b0);
-    uint32_t pc[16], mine = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int p0 = tid * 16 + q * 4;
-        uint4 x = make_uint4(0, 0, 0, 0);
-        if (p0 < pg.n) x = *reinterpret_cast<const uint4*>(&ws->piece_counts[p0]);     // (entries >= pg.n inside a quad: masked below)
-        pc[q * 4] = p0 < pg.n ? x.x : 0u; pc[q * 4 + 1] = p0 + 1 < pg.n ? x.y : 0u;
-        pc[q * 4 + 2] = p0 + 2 < pg.n ? x.z : 0u; pc[q * 4 + 3] = p0 + 3 < pg.n ? x.w : 0u;
-        mine += pc[q * 4] + pc[q * 4 + 1] + pc[q * 4 + 2] + pc[q * 4 + 3];
-    }
-    uint32_t ptotal;
-    uint32_t pex = block_excl_scan(mine, s_part, &ptotal);
-    if (mine && pex <= within && within < pex + mine) {       // the first piece whose inclusive count exceeds `within`
-        int P = tid * 16;
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            if (within >= pex + pc[j]) { pex += pc[j]; P = tid * 16 + j + 1; }
-            else break;
-        }
-        s_res[2] = (uint32_t)P; s_res[3] = within - pex;
-    }
-    if (tid == 0 && within >= ptotal) { s_res[2] = (uint32_t)pg.n; s_res[3] = 0; }      // (stale counts: cannot happen; keeps the read defined)
-    __syncthreads();
-    const int64_t P = (int64_t)s_res[2];
-    const uint32_t pin = s_res[3];
-    int64_t p0 = b0 + P * pg.tiles_per * 64, p1 = p0 + pg.tiles_per * 64;
-    if (p0 > b1) p0 = b1;
-    if (p1 > b1) p1 = b1;
-    if (pin == 0) { t.rs = t.re = p0; return; }
-    t.rs = p0; t.re = p1; t.need_in = pin;
+    const uint32_t v = (int)threadIdx.x < g.G ? ws->seg_ties[threadIdx.x] : 0u;
+    cut_from_seg_ties(v, need - st->tie_base, g, n_items, s_part, s_res);
+    t.cut_lo = s_res[0]; t.cut_hi = s_res[1]; t.within = s_res[2];
 }
 
-// prune bits of one lane item (bit j = element j goes); `item` is the lane's item, lanes of a wave hold one 64-item tile
-template <int DT, bool FAST>
-__device__ __forceinline__ uint32_t thr_prune_bits(const uint32_t* raw, bool valid, int64_t item, const ThrCtx& t)
+// prune bits of one lane item of a RANKED tile (bit j = element j goes): everything below tau, and the ties whose rank
+// (flat order inside the cut segment) is below `within`; the 64 lanes of the wave hold one tile
+template <int DT>
+__device__ __forceinline__ uint32_t thr_rank_bits(const uint32_t* raw, bool valid, const ThrCtx& t)
 {
     constexpr int VEC = Traits<DT>::VEC;
-    const int lane = threadIdx.x & 63;
-    const int64_t tile0 = uniform64(item - lane);
     uint32_t ltm = 0, eqm = 0;
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
@@ -376,27 +355,67 @@ __device__ __forceinline__ uint32_t thr_prune_bits(const uint32_t* raw, bool val
         eqm |= (uint32_t)(key == t.tau) << j;
     }
     if (!valid) eqm = 0;
-    if (!t.on) return 0;
-    if (tile0 >= t.re) return ltm;                          // behind the region: ties stay
-    if (tile0 < t.rs) return ltm | eqm;                     // in front of it: ties go
-    // inside: ties in the region before this tile (re-read; the region is one tile unless the tensor is huge or the
-    // resolve launch had to give up on piece counts), then a wave scan of this tile's own
-    uint32_t before = 0;
-    for (int64_t it = t.rs + lane; it < tile0; it += 64) {
-        uint32_t r[VEC];
-        sweep_load<DT, FAST>(t.in, it, (t.numel + VEC - 1) / VEC, t.numel, r);
-        before += count_eq<DT>(r, t.tau);
-    }
-    before = wave_sum(before);
     uint32_t prune = ltm;
     const uint32_t cnt = __popc(eqm);
     const uint32_t incl = wave_incl_scan(cnt);
-    uint32_t r = before + incl - cnt;
+    uint32_t r = t.before + incl - cnt;
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-        if ((eqm >> j) & 1u) { if (r < t.need_in) prune |= 1u << j; r++; }
+        if ((eqm >> j) & 1u) { if (r < t.within) prune |= 1u << j; r++; }
     }
     return prune;
+}
+
+// A cut workgroup (blockIdx.x < kCutWGs, 256 threads) walks its share of the cut segment's tiles: first the ties in front of
+// its first tile (strided re-read with eight independent loads per thread in flight), then its tiles in groups of four (one per
+// wave) with the running tie count handed from group to group.  process(item, raw, valid, before) is called once per lane item.
+template <int DT, bool FAST, class F>
+__device__ __forceinline__ void cut_wg_run(const ThrCtx& t, const void* in, int64_t numel, int64_t n_items, uint32_t* s_x, F&& process)
+{
+    constexpr int VEC = Traits<DT>::VEC;
+    if (!t.on || t.cut_lo >= t.cut_hi) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t nB = (t.cut_hi - t.cut_lo + 63) / 64;
+    const int64_t T = (nB + kCutWGs - 1) / kCutWGs;
+    const int64_t g0 = (int64_t)blockIdx.x * T, g1 = g0 + T < nB ? g0 + T : nB;
+    if (g0 >= g1) return;                                                    // (block-uniform)
+    uint32_t c = 0;
+    {
+        int64_t it = t.cut_lo + tid;
+        const int64_t end = t.cut_lo + g0 * 64;
+        for (; it + 7 * 256 < end; it += 8 * 256) {
+            uint32_t r[8][VEC];
+#pragma unroll
+            for (int u = 0; u < 8; u++) sweep_load<DT, FAST>(in, it + u * 256, n_items, numel, r[u]);
+#pragma unroll
+            for (int u = 0; u < 8; u++) c += count_eq<DT>(r[u], t.tau);
+        }
+        for (; it < end; it += 256) {
+            uint32_t r[VEC];
+            sweep_load<DT, FAST>(in, it, n_items, numel, r);
+            c += count_eq<DT>(r, t.tau);
+        }
+    }
+    c = wave_sum(c);
+    if (lane == 0) s_x[wave] = c;
+    __syncthreads();
+    uint32_t running = s_x[0] + s_x[1] + s_x[2] + s_x[3];
+    for (int64_t g = g0; g < g1; g += 4) {                                   // (block-uniform trip count)
+        const int64_t tile = g + wave;
+        const bool active = tile < g1;
+        const int64_t item = t.cut_lo + tile * 64 + lane;
+        const bool valid = active && item < n_items;
+        uint32_t raw[VEC];
+        sweep_load<DT, FAST>(in, item, n_items, numel, raw);
+        const uint32_t mine = wave_sum(valid ? count_eq<DT>(raw, t.tau) : 0u);
+        __syncthreads();                                                     // (s_x read by everybody)
+        if (lane == 0) s_x[wave] = active ? mine : 0u;
+        __syncthreads();
+        uint32_t before = running;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const uint32_t x = s_x[w]; before += w < wave ? x : 0u; running += x; }
+        if (active) process(item, raw, valid, before);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -31,22 +31,20 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
     // (the tables are filled further down, behind the first tile's load: one memory round trip for everything)
 
     const bool do_quant = a.lpb > 0;
-    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    constexpr int kLead = NM == -1 ? kCutWGs : 0;                 // threshold mode: the first workgroups of the grid own the cut segment
+    const int64_t stride = (int64_t)(gridDim.x - kLead) * kThreads;
     const int64_t n_round = (a.n_items + kThreads - 1) / kThreads * kThreads;   // uniform trip count per block
     const uint4* __restrict__ src = reinterpret_cast<const uint4*>(a.in);
 
     // N:M mask on the 4 dwords of an item (16-bit dtypes: 2 groups of 4; fp32: 1 group)
     ThrCtx thr;
     bool item_valid = true;
-    int64_t item_index = 0;
     auto nm_mask = [&](uint32_t& d0, uint32_t& d1, uint32_t& d2, uint32_t& d3) __attribute__((always_inline)) {
         if constexpr (NM == -1) {                       // global magnitude threshold (unstructured, bfp_ops.py:61-71)
-            const int64_t tile0 = uniform64(item_index - (threadIdx.x & 63));      // the wave's 64 lanes hold one aligned tile
-            const bool ranked = tile0 >= thr.rs && tile0 < thr.re;
-            if (__builtin_expect(!ranked, 1)) {
-                // every tile but (normally) one: the ties of this tile all go (in front of the cut) or all stay, i.e. one
-                // comparison against tau + 1 or tau
-                const uint32_t teff = thr.tau + (tile0 < thr.rs ? 1u : 0u);     // (tau == 0 when nothing is pruned at all)
+            if (__builtin_expect(!thr.ranked, 1)) {
+                // ordinary workgroups: the ties of this tile all go (in front of the cut segment) or all stay, i.e. one
+                // comparison against tau + 1 or tau (thr.teff, set per tile by the caller; tau == 0 when nothing is pruned)
+                const uint32_t teff = thr.teff;
                 if constexpr (VEC == 8) {
                     // packed: keys <= 0x7f81 and teff <= 0x7f82, so teff - 1 - key fits 16 signed bits; its sign says keep
                     const uint32_t absm = T::ABS | (T::ABS << 16), nanc = (T::INF + 1u) | ((T::INF + 1u) << 16);
@@ -57,14 +55,14 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
                     d0 = mag_key<DT>(d0) < teff ? 0u : d0; d1 = mag_key<DT>(d1) < teff ? 0u : d1;
                     d2 = mag_key<DT>(d2) < teff ? 0u : d2; d3 = mag_key<DT>(d3) < teff ? 0u : d3;
                 }
-            } else {
+            } else {                                    // cut workgroups: rank the ties of the tile
                 uint32_t raw[VEC];
                 if constexpr (VEC == 4) { raw[0] = d0; raw[1] = d1; raw[2] = d2; raw[3] = d3; }
                 else {
                     raw[0] = d0 & 0xffffu; raw[1] = d0 >> 16; raw[2] = d1 & 0xffffu; raw[3] = d1 >> 16;
                     raw[4] = d2 & 0xffffu; raw[5] = d2 >> 16; raw[6] = d3 & 0xffffu; raw[7] = d3 >> 16;
                 }
-                const uint32_t prune = thr_prune_bits<DT, true>(raw, item_valid, item_index, thr);
+                const uint32_t prune = thr_rank_bits<DT>(raw, item_valid, thr);
                 if constexpr (VEC == 4) {
                     d0 = (prune & 1u) ? 0u : d0; d1 = (prune & 2u) ? 0u : d1; d2 = (prune & 4u) ? 0u : d2; d3 = (prune & 8u) ? 0u : d3;
                 } else {
@@ -226,8 +224,15 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
         constexpr bool GUARD = decltype(guard_tag)::value;
         const bool valid = !GUARD || item < n_limit;
         item_valid = valid;
-        item_index = item;
         uint32_t d0 = cur.x, d1 = cur.y, d2 = cur.z, d3 = cur.w;
+        [[maybe_unused]] bool cut_skip = false;                   // NM == -1, ordinary workgroup on a tile of the cut segment: its store goes to the dump
+        if constexpr (NM == -1) {
+            if (!thr.ranked) {
+                const int64_t tile0 = uniform64(item - (threadIdx.x & 63));     // the wave's 64 lanes hold one aligned tile
+                thr.teff = thr.tau + (tile0 < thr.cut_lo ? 1u : 0u);
+                cut_skip = tile0 >= thr.cut_lo && tile0 < thr.cut_hi;
+            }
+        }
 
 #ifdef BFPQ_COPYONLY          /* A/B knob: same loop, loads and stores only (ceiling for this launch geometry) */
         if (valid && a.out_deq) stream_store(reinterpret_cast<uint4*>(a.out_deq) + item, make_uint4(d0, d1, d2, d3));
@@ -463,6 +468,7 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
             return;
         }
         if constexpr (USE_BUF) { buf_res = make_uint4(o0, o1, o2, o3); return; }   // (the sweep stores it)
+        if constexpr (F32IMG && NM == -1) { if (cut_skip) return; }
         if constexpr (F32IMG) {
             // the fp32 image of the result and nothing else (what 'stoc' rounding of a half tensor returns): two
             // unconditional-in-form stores per item, like the drop-in mode's one
@@ -479,10 +485,13 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
             return;
         }
         if constexpr (DEQ_ONLY) {                                           // hot mode: exactly one store per item
-            if (valid) stream_store(reinterpret_cast<uint4*>(out_deq) + item, make_uint4(o0, o1, o2, o3));
+            uint4* dst = reinterpret_cast<uint4*>(out_deq) + item;
+            if constexpr (NM == -1) dst = cut_skip ? thr.dump + (threadIdx.x & 63) : dst;       // (keeps the store unconditional in form)
+            if (valid) stream_store(dst, make_uint4(o0, o1, o2, o3));
             return;
         }
         if (!valid) return;
+        if constexpr (NM == -1) { if (cut_skip) return; }
         if (a.out_deq) stream_store(reinterpret_cast<uint4*>(a.out_deq) + item, make_uint4(o0, o1, o2, o3));
         if (a.out_codes) {
             int c[VEC];
@@ -685,7 +694,8 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
         return __builtin_nontemporal_load(reinterpret_cast<const u4v*>(src + (i < last ? i : last)));
     };
     const int64_t full = a.n_items / stride;                               // sweeps in which every thread has an item
-    int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const bool cut_wg = NM == -1 && (int)blockIdx.x < kLead;
+    int64_t item = cut_wg ? (int64_t)threadIdx.x : (int64_t)((int)blockIdx.x - kLead) * kThreads + threadIdx.x;
     u4v c0 = fetch(item);
     // Tables -> LDS, issued BEHIND the first tile's load and as one dword per thread.  The byte-per-thread loops this
     // replaces were 5 dependent global round trips (3 for the 729-byte N:M table, 2 for the window table) in front of the
@@ -723,7 +733,18 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
     if constexpr (NM == -1) {
         __shared__ uint32_t s_part[16];
         __shared__ uint32_t s_res[8];
-        thr_setup<DT>(thr, a.selws, a.in, a.n_items * VEC, a.n_items, s_part, s_res);
+        thr_setup<DT>(thr, a.selws, a.n_items, s_part, s_res);
+        if (cut_wg) {
+            // this workgroup owns a share of the cut segment's tiles: ties in front of them counted, then each tile ranked
+            cut_wg_run<DT, true>(thr, a.in, a.n_items * VEC, a.n_items, s_part, [&](int64_t it, const uint32_t* raw, bool, uint32_t before) __attribute__((always_inline)) {
+                thr.ranked = true; thr.before = before;
+                uint4 cur;
+                if constexpr (VEC == 4) cur = make_uint4(raw[0], raw[1], raw[2], raw[3]);
+                else cur = make_uint4(raw[0] | (raw[1] << 16), raw[2] | (raw[3] << 16), raw[4] | (raw[5] << 16), raw[6] | (raw[7] << 16));
+                body(std::true_type{}, it, cur);
+            });
+            return;
+        }
     }
     // One more memory op behind the first load, result unused.  At the loop top the back edge arrives with [load, store]
     // outstanding and the entry edge with [load] only; one s_waitcnt immediate must serve both edges, so the compiler
@@ -849,7 +870,7 @@ int launch_fused_mx8(const FusedArgs& a, hipStream_t s)
 template <int DT>
 int launch_fused_threshold(const FusedArgs& a, hipStream_t s)
 {
-    const dim3 grid(grid_for(a.n_items)), block(kThreads);
+    const dim3 grid(kCutWGs + grid_for(a.n_items)), block(kThreads);        // (the cut segment's workgroups come first)
     const bool deq_only = a.out_deq && !a.out_codes && !a.out_exp;
     if (a.seed) {
         hipLaunchKernelGGL((k_fused_flat<DT, -1, true, true, -1, false>), grid, block, 0, s, a);

@@ -1,6 +1,7 @@
-// bfpq_unstructured.hip -- the unstructured (global magnitude threshold) path of libbfpq.so: histogram, resolve and
-// prune-only apply launches + their C-ABI entry points (include/bfpq.h).  The fused prune+quantize apply is
-// k_fused_flat<.., -1, ..> in bfpq_kernels.hip.  Reference: src/transformers/bfp/bfp_ops.py:61-71.
+// bfpq_unstructured.hip -- the unstructured (global magnitude threshold) path of libbfpq.so: the histogram launch (with the
+// resolve step folded into its last workgroup on a single device), the resolve launch of the multi-GPU / fp32 launch-pair
+// form, the prune-only apply launch, and their C-ABI entry points (include/bfpq.h).  The fused prune+quantize apply is
+// k_fused_flat<.., -1, ..> in bfpq_fused.h.  Reference: src/transformers/bfp/bfp_ops.py:61-71.
 #include <hip/hip_runtime.h>
 #include "bfpq.h"
 #include "bfpq_common.h"
@@ -21,16 +22,137 @@ __device__ unsigned long long g_stamps[3][512][8];
 #define STAMP(kern, idx) do { } while (0)
 #endif
 
+// words that one workgroup hands to another INSIDE a launch (segment windows -> the resolving workgroup) travel as
+// agent-scope relaxed atomics: write-through stores, cache-bypassing loads, no fences (cdna_hip_programming.md, guideline 16 R1)
+__device__ __forceinline__ void pub_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t pub_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ---------------------------------------------------------------------------------------------
+// The resolve step inside the histogram launch (single device, 16-bit dtypes): run by the LAST workgroup to draw its ticket,
+// i.e. when every segment's coarse counts and window are in memory.  1024 threads; lds: the (finished) histogram's LDS.
+//   coarse bins (8 copies) -> scan -> the coarse bin C that holds the k-th key
+//   every segment's window slice for C (one agent-scope load per segment and fine bin, 32 per thread, all independent)
+//     -> their sum is the global fine histogram of C -> scan -> tau; the column of tau is every segment's tie count
+//     -> scan -> the cut segment
+// A segment whose window does not cover C although it has magnitudes outside its window is counted again here (one
+// workgroup: slow, correct, and only for tensors whose segments live on wildly different scales).
+// ---------------------------------------------------------------------------------------------
+template <int DT, bool FAST>
+__device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int64_t n_items, const SegGeom g, int64_t k, SelWs* ws, uint32_t* lds)
+{
+    constexpr int VEC = Traits<DT>::VEC;
+    constexpr int NC = BFPQ_SELECT_HIST_COPIES;
+    uint32_t* s_segwin = lds;            // [256]
+    uint32_t* s_tc = lds + 256;          // [256]
+    uint32_t* s_fine = lds + 512;        // [8][128]
+    uint32_t* s_part = lds + 1536;       // [16]
+    uint32_t* s_r = lds + 1552;          // [16]
+    uint32_t* s_h = lds + 1568;          // [128]
+    const int t = threadIdx.x;
+    uint32_t cv = 0;
+    if (t < kCoarseBins) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) cv += pub_load(&ws->coarse[c][t]);
+    }
+    const uint32_t sw = t < g.G ? pub_load(&ws->seg_win[t]) : 0u;
+    __syncthreads();                                         // (the histogram's LDS is dead from here on)
+    if (t < kMaxSeg) s_segwin[t] = sw;
+    if (t < 16) s_r[t] = 0;
+    const uint32_t k_rem = (uint32_t)k;
+    uint32_t total;
+    uint32_t excl = block_excl_scan(cv, s_part, &total);     // (its barriers also order the resets above)
+    if (cv && excl < k_rem && k_rem <= excl + cv) { s_r[0] = (uint32_t)t; s_r[1] = excl; }
+    __syncthreads();
+    const uint32_t C = s_r[0], before = s_r[1];              // (k == 0: bin 0, nothing in front of it)
+    for (int i = t; i < NC * kCoarseBins; i += kSelThreads) (&ws->coarse[0][0])[i] = 0u;     // zero for the next call
+    // segments whose window cannot answer for C
+    int miss = 0;
+    if (t < g.G) {
+        const uint32_t clo = (sw & 0x3fffffffu) >> 7;
+        if (!(C - clo < (uint32_t)(kWinBins / 128)) && (sw >> 31)) miss = 1;
+    }
+    if (__syncthreads_or(miss)) {
+        if (t < kMaxSeg) s_tc[t] = (uint32_t)miss;
+        __syncthreads();
+        for (int s = 0; s < g.G; s++) {
+            if (!s_tc[s]) continue;                          // (block-uniform)
+            if (t < 128) s_h[t] = 0;
+            __syncthreads();
+            const int64_t i0 = (int64_t)s * g.L, i1 = i0 + g.L < n_items ? i0 + g.L : n_items;
+            for (int64_t it = i0 + t; it < i1; it += kSelThreads) {
+                uint32_t r[VEC];
+                sweep_load<DT, FAST>(in, it, n_items, numel, r);
+#pragma unroll
+                for (int j = 0; j < VEC; j++) {
+                    const uint32_t key = mag_key<DT>(r[j]);
+                    if ((FAST || it * VEC + j < numel) && (key >> 7) == C) atomicAdd(&s_h[key & 127u], 1u);
+                }
+            }
+            __syncthreads();
+            if (t < 128) pub_store(&ws->windows[s][t], s_h[t]);
+            if (t == 0) s_segwin[s] = (C << 7) | (1u << 30);                 // a 128-bin window at C
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    // window slices: thread (sg, f) reads fine bin f of C from the segments sg, sg + 8, ...
+    const int sg = t >> 7, f = t & 127;
+    uint32_t cnt[kMaxSeg / 8], sum = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxSeg / 8; j++) {
+        const int s = sg + 8 * j;
+        uint32_t v = 0;
+        if (s < g.G) {
+            const uint32_t w = s_segwin[s], clo = (w & 0x3fffffffu) >> 7;
+            const bool narrow = (w >> 30) & 1u;
+            if (narrow ? clo == C : C - clo < (uint32_t)(kWinBins / 128)) v = pub_load(&ws->windows[s][(narrow ? 0u : (C - clo) * 128u) + (uint32_t)f]);
+        }
+        cnt[j] = v;
+        sum += v;
+    }
+    s_fine[sg * 128 + f] = sum;
+    __syncthreads();
+    uint32_t fv = 0;
+    if (t < 128) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) fv += s_fine[q * 128 + t];
+    }
+    excl = before + block_excl_scan(fv, s_part, &total);
+    if (fv && excl < k_rem && k_rem <= excl + fv) { s_r[2] = (C << 7) + (uint32_t)t; s_r[3] = excl; s_r[4] = fv; }
+    __syncthreads();
+    const uint32_t tau = s_r[2], run = s_r[3], ties = s_r[4];
+    const uint32_t need = k_rem - run;
+    // the column of tau: every segment's tie count
+    if (f == (int)(tau & 127u)) {
+#pragma unroll
+        for (int j = 0; j < kMaxSeg / 8; j++) s_tc[sg + 8 * j] = cnt[j];
+    }
+    __syncthreads();
+    const uint32_t tc = t < g.G ? s_tc[t] : 0u;
+    cut_from_seg_ties(tc, (int64_t)need, g, n_items, s_part, s_r + 8);
+    if (t == 0) {
+        bfpq_select_state* st = &ws->st;
+        st->prefix = tau; st->prefix_mask = 0x7fffu; st->k_rem = (int64_t)need; st->tau = tau; st->done = 1;
+        st->need = (int64_t)need; st->ties = (int64_t)ties; st->k = k; st->tie_base = 0;
+        st->flags = 1u; st->cut_lo = s_r[8]; st->cut_hi = s_r[9]; st->cut_within = s_r[10];
+        st->reserved[0] = st->reserved[1] = 0;
+        ws->ticket = 0u;                                     // ready for the next call
+    }
+}
+
 // Launch 1: histogram of the current digit.  One workgroup per flat-contiguous segment (see the block comment at ThrCtx);
-// LDS histogram (32 768 bins = 128 KB for 16-bit keys), non-zero bins flushed by integer atomics (deterministic).  On the
-// pass that decides the threshold the workgroup also leaves a window of its private histogram in the workspace.
+// LDS histogram (32 768 bins = 128 KB for 16-bit keys).  On the pass that decides the threshold the workgroup also leaves a
+// window of its private histogram in the workspace.
+//   fuse != 0 (single device, 16-bit dtypes): only the 256 coarse sums go to the global histogram; the workgroup publishes
+//     its window, draws a ticket, and the last one resolves the selection (fused_resolve) -- one launch.
+//   fuse == 0: the non-zero fine bins are flushed by integer atomics (deterministic) for the resolve launch.
 template <int DT, bool FAST>
 __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int64_t numel, int pass, int shift, int nbits, int first, int last,
-                                                             SelWs* ws, uint32_t* hist_ext, int64_t k, int64_t numel_global)
+                                                             SelWs* ws, uint32_t* hist_ext, int64_t k, int64_t numel_global, int fuse)
 {
     using T = Traits<DT>;
     constexpr int VEC = T::VEC;
-    extern __shared__ uint32_t s_hist[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
     uint32_t* hist = hist_ext ? hist_ext : ws->hist[pass][0];
     __shared__ __attribute__((aligned(16))) uint32_t s_coarse[kCoarseBins];
     __shared__ uint32_t s_res[4];
@@ -83,7 +205,8 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
     STAMP(0, 1);
     __syncthreads();
     STAMP(0, 2);
-    hist += (size_t)(blockIdx.x % BFPQ_SELECT_HIST_COPIES) * BFPQ_SELECT_HIST_ENTRIES;
+    const int copy = blockIdx.x % BFPQ_SELECT_HIST_COPIES;
+    hist += (size_t)copy * BFPQ_SELECT_HIST_ENTRIES;
     const bool windows = last && nbits == 15;
     if (nbits == 15) {
         // coarse histogram (256 bins of 128): four threads per coarse bin, each sums 32 bins with 16-byte LDS reads in a
@@ -97,7 +220,7 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
         }
         sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
         sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
-        if (r == 0) { s_coarse[q] = sum; if (sum) atomicAdd(&hist[kFineBins + q], sum); }
+        if (r == 0) { s_coarse[q] = sum; if (sum) atomicAdd(fuse ? &ws->coarse[copy][q] : &hist[kFineBins + q], sum); }
         __syncthreads();
     }
     STAMP(0, 3);
@@ -121,13 +244,14 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
             uint32_t inside = 0;
             for (int j = 0; j < kWinBins / 128; j++) inside += s_coarse[clo + j];
             s_res[0] = (uint32_t)clo * 128u;
-            ws->seg_win[blockIdx.x] = ((uint32_t)clo * 128u) | (inside != seg_elems ? 0x80000000u : 0u);
+            pub_store(&ws->seg_win[blockIdx.x], ((uint32_t)clo * 128u) | (inside != seg_elems ? 0x80000000u : 0u));
         }
+        if (seg_elems == 0 && t == 0) pub_store(&ws->seg_win[blockIdx.x], 0u);          // (an empty segment: no window, nothing outside it)
     }
     // flush of the non-zero bins by integer atomics (deterministic) into this workgroup's COPY of the histogram: with
     // all workgroups adding into one copy every hot address takes 256 serialised adds (~3 us behind the streaming loop).
-    // The LDS reads of a thread are issued together.
-    if (nbits == 15) {
+    // The LDS reads of a thread are issued together.  (Not in the fused launch: its resolve step sums the windows.)
+    if (nbits == 15 && !fuse) {
         // one coarse bin (128 fine bins, two 256-byte atomic wave-instructions) per wave and trip; the empty ones -- all but
         // 15-20 of the 256 for a weight tensor -- are skipped on their coarse sum
         const int lane = t & 63;
@@ -138,7 +262,7 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
             if (c0) atomicAdd(&hist[i], c0);
             if (c1) atomicAdd(&hist[i + 64], c1);
         }
-    } else {
+    } else if (nbits != 15) {
         for (int i = t; i < nbins; i += kSelThreads) {
             const uint32_t c = s_hist[i];
             if (c) atomicAdd(&hist[i], c);
@@ -153,17 +277,28 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
     }
     __syncthreads();
     const int lo = (int)s_res[0];
-    ws->windows[blockIdx.x][t] = s_hist[lo + t];
-    ws->windows[blockIdx.x][kSelThreads + t] = s_hist[lo + kSelThreads + t];
+    pub_store(&ws->windows[blockIdx.x][t], s_hist[lo + t]);
+    pub_store(&ws->windows[blockIdx.x][kSelThreads + t], s_hist[lo + kSelThreads + t]);
     STAMP(0, 5);
+    if (!fuse) return;
+    // publish: every storing wave drains, the workgroup meets, one lane draws the ticket; the last workgroup resolves
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) s_res[1] = __hip_atomic_fetch_add(&ws->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    if (!s_res[1]) return;
+    STAMP(0, 6);
+    fused_resolve<DT, FAST>(in, numel, n_items, g, k, ws, s_hist);
+    STAMP(0, 7);
 }
 
-// Launch 2: one workgroup (256 threads) per segment, every one of them repeats the (tiny) selection: which digit holds
-// the k-th smallest key.  hist_all: n_hists histograms of BFPQ_SELECT_HIST_ENTRIES words -- BFPQ_SELECT_HIST_COPIES per
-// rank, rank-major (an all-gather of the per-rank buffers; one rank: the local buffer) -- summed on the fly; on the deciding
-// pass the per-rank counts of the threshold bin also give, without a second exchange, the ties that lower ranks hold.
-// On the deciding pass: tie count of the own segment (window, or recount), piece counts of the segment that holds the
-// cut.  Zeroes zero_buf (multi-GPU: the local histogram buffer, which this launch does not read -- it reads the gathered copy).
+// Launch 2 of the launch-pair form (multi-GPU: between them the all-gather of the histograms; fp32: three pairs): one
+// workgroup (256 threads) per segment, every one of them repeats the (tiny) selection: which digit holds the k-th smallest
+// key.  hist_all: n_hists histograms of BFPQ_SELECT_HIST_ENTRIES words -- BFPQ_SELECT_HIST_COPIES per rank, rank-major (an
+// all-gather of the per-rank buffers; one rank: the local buffer) -- summed on the fly; on the deciding pass the per-rank
+// counts of the threshold bin also give, without a second exchange, the ties that lower ranks hold, the windows give every
+// segment's tie count, and their scan the cut segment.  Zeroes zero_buf (multi-GPU: the local histogram buffer, which this
+// launch does not read -- it reads the gathered copy).
 constexpr int kResThreads = 256;
 template <int DT, bool FAST>
 __global__ void __launch_bounds__(kResThreads) k_select_resolve(const void* in, int64_t numel, int pass, int shift, int nbits, int first, int last,
@@ -245,7 +380,7 @@ __global__ void __launch_bounds__(kResThreads) k_select_resolve(const void* in, 
     uint32_t tc = 0;
     int miss = 0;
     if (t < g.G) {
-        const uint32_t rel = digit - (wb & 0x7fffffffu);
+        const uint32_t rel = digit - (wb & 0x3fffffffu);
         if (rel < (uint32_t)W) tc = ws->windows[t][rel];
         else if (wb >> 31) miss = 1;
     }
@@ -254,39 +389,12 @@ __global__ void __launch_bounds__(kResThreads) k_select_resolve(const void* in, 
     STAMP(1, 3);
     const bool mine_seg = t == (int)blockIdx.x;
     if (mine_seg) s_res[5] = (uint32_t)miss;
-    uint32_t local_total;
-    const uint32_t excl = block_excl_scan(tc, s_part, &local_total);        // (barriers: s_res[5] visible)
+    __syncthreads();
     if (!any_miss) {
-        if (mine_seg) ws->seg_ties[t] = tc;
-        const bool ranked = k0 > 0 && need > 0 && need < cnt;
-        const int64_t local_need = (int64_t)need - tie_base;
-        if (ranked && local_need > 0 && local_need < (int64_t)local_total) {
-            if (tc && (int64_t)excl <= local_need && local_need < (int64_t)excl + tc) { s_res[6] = (uint32_t)t; s_res[7] = (uint32_t)(local_need - excl); }
-            __syncthreads();
-            const int B = (int)s_res[6];
-            if (s_res[7] != 0) {
-                // ties per piece of segment B: one wave per piece, the grid's waves share the pieces
-                const int64_t b0 = (int64_t)B * g.L, b1 = b0 + g.L < n_items ? b0 + g.L : n_items;
-                const PieceGeom pg = piece_geom(b1 - b0);
-                const int lane = t & 63;
-                for (int q = blockIdx.x * (kResThreads / 64) + (t >> 6); q < pg.n; q += gridDim.x * (kResThreads / 64)) {
-                    const int64_t it0 = b0 + (int64_t)q * pg.tiles_per * 64;
-                    int64_t it1 = it0 + pg.tiles_per * 64;
-                    if (it1 > b1) it1 = b1;
-                    uint32_t c = 0;
-                    for (int64_t it = it0 + lane; it < it1; it += 64) {
-                        uint32_t r[VEC];
-                        sweep_load<DT, FAST>(in, it, n_items, numel, r);
-                        c += count_eq<DT>(r, tau);
-                    }
-                    c = wave_sum(c);
-                    if (lane == 0) ws->piece_counts[q] = c;
-                }
-            }
-        }
+        cut_from_seg_ties(tc, (int64_t)need - (int64_t)tie_base, g, n_items, s_part, s_res + 8);     // (every workgroup: the same numbers)
     } else {
         // some segment's window does not cover the threshold: every such segment counts its ties again (its own
-        // workgroup, so no workgroup waits for another); the apply launch then ranks the whole segment that holds the cut
+        // workgroup, so no workgroup waits for another); the apply launch then finds the cut from seg_ties
         if (s_res[5]) {
             const int64_t i0 = (int64_t)blockIdx.x * g.L, i1 = i0 + g.L < n_items ? i0 + g.L : n_items;
             uint32_t c = 0;
@@ -305,11 +413,14 @@ __global__ void __launch_bounds__(kResThreads) k_select_resolve(const void* in, 
         st->prefix = prefix; st->prefix_mask = pmask0 | (((1u << nbits) - 1u) << shift);
         st->k_rem = (int64_t)need; st->tau = tau; st->done = 1;
         st->need = (int64_t)need; st->ties = (int64_t)cnt; st->k = k0;
-        st->tie_base = (int64_t)tie_base; st->flags = (any_miss ? 0u : 1u) | (own_hist ? 2u : 0u); st->reserved = 0;
+        st->tie_base = (int64_t)tie_base; st->flags = (any_miss ? 0u : 1u) | (own_hist ? 2u : 0u);
+        st->cut_lo = any_miss ? 0u : s_res[8]; st->cut_hi = any_miss ? 0u : s_res[9]; st->cut_within = any_miss ? 0u : s_res[10];
+        st->reserved[0] = st->reserved[1] = 0;
     }
 }
 
-// Launch 3 (prune only: q -> s order, ragged shapes; the fused quantizer is k_fused_flat<.., -1, ..>)
+// Launch 3 (prune only: q -> s order, ragged shapes; the fused quantizer is k_fused_flat<.., -1, ..>).  The first kCutWGs
+// workgroups own the cut segment, the others sweep the tensor and leave that segment's tiles alone.
 template <int DT, bool FAST>
 __global__ void __launch_bounds__(kThreads) k_threshold_apply(const void* in, void* out, int64_t numel, SelWs* ws)
 {
@@ -319,31 +430,50 @@ __global__ void __launch_bounds__(kThreads) k_threshold_apply(const void* in, vo
     __shared__ uint32_t s_res[8];
     const int64_t n_items = (numel + VEC - 1) / VEC;
     const int64_t n_round = (n_items + 63) / 64 * 64;
-    const int64_t stride = (int64_t)gridDim.x * kThreads;
-    int64_t item = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const bool cut_wg = (int)blockIdx.x < kCutWGs;
+    const int64_t stride = (int64_t)(gridDim.x - kCutWGs) * kThreads;
+    int64_t item = cut_wg ? (int64_t)threadIdx.x : (int64_t)((int)blockIdx.x - kCutWGs) * kThreads + threadIdx.x;
     uint32_t cur[VEC], nxt[VEC];
     sweep_load<DT, FAST>(in, item, n_items, numel, cur);
     ThrCtx t;
-    thr_setup<DT>(t, ws, in, numel, n_items, s_part, s_res);
+    thr_setup<DT>(t, ws, n_items, s_part, s_res);
+    auto store = [&](int64_t it, const uint32_t* raw, uint32_t prune) __attribute__((always_inline)) {
+        const int64_t e0 = it * VEC;
+        if constexpr (FAST) {
+            uint32_t r[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; j++) r[j] = ((prune >> j) & 1u) ? 0u : raw[j];
+            uint4 o;
+            if constexpr (VEC == 4) o = make_uint4(r[0], r[1], r[2], r[3]);
+            else o = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
+            reinterpret_cast<uint4*>(out)[it] = o;
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; j++)
+                if (e0 + j < numel) reinterpret_cast<raw_t*>(out)[e0 + j] = ((prune >> j) & 1u) ? (raw_t)0 : (raw_t)raw[j];
+        }
+    };
+    if (cut_wg) {
+        cut_wg_run<DT, FAST>(t, in, numel, n_items, s_part, [&](int64_t it, const uint32_t* raw, bool valid, uint32_t before) __attribute__((always_inline)) {
+            ThrCtx r = t;
+            r.ranked = true; r.before = before;
+            const uint32_t prune = thr_rank_bits<DT>(raw, valid, r);
+            if (valid) store(it, raw, prune);
+        });
+        return;
+    }
+    const int lane = threadIdx.x & 63;
     for (; item < n_round; item += stride) {                   // wave-uniform trip count
         sweep_load<DT, FAST>(in, item + stride, n_items, numel, nxt);
         const bool valid = item < n_items;
-        const uint32_t prune = thr_prune_bits<DT, FAST>(cur, valid, item, t);
-        if (valid) {
-            const int64_t e0 = item * VEC;
-            if constexpr (FAST) {
-                uint32_t r[VEC];
+        const int64_t tile0 = uniform64(item - lane);
+        const bool in_cut = tile0 >= t.cut_lo && tile0 < t.cut_hi;      // (the cut workgroups' tiles)
+        if (valid && !in_cut) {
+            const uint32_t teff = t.tau + (tile0 < t.cut_lo ? 1u : 0u);
+            uint32_t prune = 0;
 #pragma unroll
-                for (int j = 0; j < VEC; j++) r[j] = ((prune >> j) & 1u) ? 0u : cur[j];
-                uint4 o;
-                if constexpr (VEC == 4) o = make_uint4(r[0], r[1], r[2], r[3]);
-                else o = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
-                reinterpret_cast<uint4*>(out)[item] = o;
-            } else {
-#pragma unroll
-                for (int j = 0; j < VEC; j++)
-                    if (e0 + j < numel) reinterpret_cast<raw_t*>(out)[e0 + j] = ((prune >> j) & 1u) ? (raw_t)0 : (raw_t)cur[j];
-            }
+            for (int j = 0; j < VEC; j++) prune |= (uint32_t)(mag_key<DT>(cur[j]) < teff) << j;
+            store(item, cur, t.on ? prune : 0u);
         }
 #pragma unroll
         for (int j = 0; j < VEC; j++) cur[j] = nxt[j];
@@ -368,12 +498,9 @@ static bool select_args_ok(const void* in, int64_t numel, int dtype, int pass, i
     return ws && dtype >= 0 && dtype <= 2 && numel >= 0 && (in || numel == 0) && pass >= 0 && pass < bfpq_select_passes(dtype) && k >= 0;
 }
 
-int bfpq_select_hist(const void* in, int64_t numel, int dtype, int pass, int64_t k, int64_t numel_global,
-                     void* ws, uint32_t* hist, void* stream)
+static int launch_select_hist(const void* in, int64_t numel, int dtype, int pass, int64_t k, int64_t numel_global,
+                              void* ws, uint32_t* hist, int fuse, void* stream)
 {
-    if (!select_args_ok(in, numel, dtype, pass, k, ws) || numel_global < numel || k > numel_global) return BFPQ_E_ARG;
-    if (numel_global >= ((int64_t)1 << 32)) return BFPQ_E_UNSUPPORTED;
-    if (numel == 0) return 0;
     int shift, nbits;
     select_digit(dtype, pass, &shift, &nbits);
     const size_t lds = sizeof(uint32_t) << nbits;
@@ -388,13 +515,22 @@ int bfpq_select_hist(const void* in, int64_t numel, int dtype, int pass, int64_t
             const hipError_t err = hipFuncSetAttribute((const void*)k_select_hist<DT, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (err != hipSuccess) return (int)err; \
         } \
-        hipLaunchKernelGGL((k_select_hist<DT, F>), dim3(g.G), dim3(kSelThreads), lds, s, in, numel, pass, shift, nbits, first, last, w, hist, k, numel_global); \
+        hipLaunchKernelGGL((k_select_hist<DT, F>), dim3(g.G), dim3(kSelThreads), lds, s, in, numel, pass, shift, nbits, first, last, w, hist, k, numel_global, fuse); \
     } while (0)
     if (dtype == BFPQ_F32) { if (fast) BFPQ_SH(BFPQ_F32, true); else BFPQ_SH(BFPQ_F32, false); }
     else if (dtype == BFPQ_F16) { if (fast) BFPQ_SH(BFPQ_F16, true); else BFPQ_SH(BFPQ_F16, false); }
     else { if (fast) BFPQ_SH(BFPQ_BF16, true); else BFPQ_SH(BFPQ_BF16, false); }
 #undef BFPQ_SH
     return (int)hipGetLastError();
+}
+
+int bfpq_select_hist(const void* in, int64_t numel, int dtype, int pass, int64_t k, int64_t numel_global,
+                     void* ws, uint32_t* hist, void* stream)
+{
+    if (!select_args_ok(in, numel, dtype, pass, k, ws) || numel_global < numel || k > numel_global) return BFPQ_E_ARG;
+    if (numel_global >= ((int64_t)1 << 32)) return BFPQ_E_UNSUPPORTED;
+    if (numel == 0) return 0;
+    return launch_select_hist(in, numel, dtype, pass, k, numel_global, ws, hist, 0, stream);
 }
 
 int bfpq_select_resolve(const void* in, int64_t numel, int dtype, int pass, int64_t k,
@@ -420,21 +556,40 @@ int bfpq_select_resolve(const void* in, int64_t numel, int dtype, int pass, int6
     return (int)hipGetLastError();
 }
 
+// single device: all launches of the selection.  16-bit dtypes: ONE (the histogram launch, whose last workgroup resolves);
+// fp32: three histogram / resolve pairs on the histogram buffers inside ws.
+int bfpq_select(const void* in, int64_t numel, int dtype, int64_t k, void* ws, void* stream)
+{
+    if (!select_args_ok(in, numel, dtype, 0, k, ws) || k > numel) return BFPQ_E_ARG;
+    if (numel >= ((int64_t)1 << 32)) return BFPQ_E_UNSUPPORTED;
+    if (numel == 0) return 0;
+    if (dtype != BFPQ_F32) return launch_select_hist(in, numel, dtype, 0, k, numel, ws, nullptr, 1, stream);
+    for (int p = 0; p < 3; p++) {
+        int rc = launch_select_hist(in, numel, dtype, p, k, numel, ws, nullptr, 0, stream);
+        if (rc) return rc;
+        rc = bfpq_select_resolve(in, numel, dtype, p, k, nullptr, 1, 0, ws, nullptr, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 int bfpq_select_reset(void* ws, void* stream)
 {
     if (!ws) return BFPQ_E_ARG;
-    return (int)hipMemsetAsync(((SelWs*)ws)->hist, 0, sizeof(((SelWs*)ws)->hist), (hipStream_t)stream);
+    SelWs* w = (SelWs*)ws;                                     // ticket, coarse copies and the fine histograms: one contiguous block
+    return (int)hipMemsetAsync(&w->ticket, 0, offsetof(SelWs, seg_ties) - offsetof(SelWs, ticket), (hipStream_t)stream);
 }
 
 int bfpq_threshold_apply(const void* in, void* out, int64_t numel, int dtype, void* ws, void* stream)
 {
     if (!in || !out || !ws || dtype < 0 || dtype > 2 || numel < 0) return BFPQ_E_ARG;
     if (numel == 0) return 0;
+    if (in == out) return BFPQ_E_ARG;                         // (tie ranks are counted from the input while other tiles are written)
     hipStream_t s = (hipStream_t)stream;
     SelWs* w = (SelWs*)ws;
     const int vec = dtype_vec(dtype);
     const bool fast = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0 && numel % vec == 0;
-    const dim3 grid(grid_for((numel + vec - 1) / vec)), block(kThreads);
+    const dim3 grid(kCutWGs + grid_for((numel + vec - 1) / vec)), block(kThreads);
 #define BFPQ_TA(DT) do { if (fast) hipLaunchKernelGGL((k_threshold_apply<DT, true>), grid, block, 0, s, in, out, numel, w); \
                          else hipLaunchKernelGGL((k_threshold_apply<DT, false>), grid, block, 0, s, in, out, numel, w); } while (0)
     if (dtype == BFPQ_F32) BFPQ_TA(BFPQ_F32); else if (dtype == BFPQ_F16) BFPQ_TA(BFPQ_F16); else BFPQ_TA(BFPQ_BF16);

@@ -79,6 +79,8 @@ def unstructured_sparsity_sharded(local, sparsity_frac, numel_global, group=None
     assert (sparsity_frac > 0)
     eng = engine or _NativeEngine()
     k = int(numel_global * sparsity_frac)
+    if k > numel_global:
+        raise RuntimeError("selected index k out of range")             # what torch.topk raises in the reference
     ws = eng.workspace(local.device)
     eng.select_threshold(local, k, ws, numel_global=numel_global, allgather=_hist_allgather(group))
     if local.numel() == 0:
@@ -119,6 +121,9 @@ def float_to_bfp_blocked_sharded(local, rows_total, group=None, gather=False, co
         if fused:
             # threshold, then prune + quantize in ONE pass over the slab (as on a single device)
             assert (bfp_args['sparsity_frac'] > 0)
+            assert (bfp_args['block_size'] > 0)                         # bfp_ops.py:130
+            if int(numel_global * bfp_args['sparsity_frac']) > numel_global:
+                raise RuntimeError("selected index k out of range")     # what torch.topk raises in the reference
             ws = eng.workspace(local.device)
             eng.select_threshold(local, int(numel_global * bfp_args['sparsity_frac']), ws, numel_global=numel_global,
                                  allgather=_hist_allgather(group))

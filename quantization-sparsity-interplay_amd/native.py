@@ -24,7 +24,7 @@ EXP_WIN_ENTRIES = 320
 NM4_LUT_ENTRIES = 729
 NM8_LUT_ENTRIES = 1 << 24
 USE_NM8_TABLE = True               # False: N:8 groups with straddling ties replay nth_element in the kernel (tests)
-SELECT_STATE_BYTES = 64
+SELECT_STATE_BYTES = 80
 SELECT_HIST_ENTRIES = 32768 + 256
 SELECT_HIST_COPIES = 8
 
@@ -81,6 +81,7 @@ def load_library():
         L.bfpq_select_passes.argtypes = [i32]
         L.bfpq_select_ws_bytes.argtypes = []
         L.bfpq_select_ws_bytes.restype = i64
+        L.bfpq_select.argtypes = [vp, i64, i32, i64, vp, vp]
         L.bfpq_select_hist.argtypes = [vp, i64, i32, i32, i64, i64, vp, vp, vp]
         L.bfpq_select_resolve.argtypes = [vp, i64, i32, i32, i64, vp, i32, i32, vp, vp, vp]
         L.bfpq_threshold_apply.argtypes = [vp, vp, i64, i32, vp, vp]
@@ -101,7 +102,7 @@ def load_library():
         L.bfpq_hbfp_linear_mx8_parts.argtypes = [i64, i64, i64]
         L.bfpq_hbfp_linear_mx8_splitk.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, i64, i32, vp]
         for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_is_fused", "bfpq_nm_sparsify",
-                     "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
+                     "bfpq_select_passes", "bfpq_select", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
                      "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize", "bfpq_hbfp_linear_slices",
                      "bfpq_hbfp_linear_decode", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled",
                      "bfpq_mx8_from_hbfp", "bfpq_quantize_mx8", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8",
@@ -113,7 +114,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_mx8_parts", "bfpq_hbfp_linear_mx8_splitk", "bfpq_quantize_mx8", "bfpq_mx8_from_hbfp", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_select_ws_bytes", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_is_fused", "bfpq_nm_sparsify",
-                    "bfpq_select_passes", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
+                    "bfpq_select_passes", "bfpq_select", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
                     "bfpq_threshold_apply", "bfpq_quantize_threshold")
 
 
@@ -356,8 +357,10 @@ class FastQuant:
 
 class PreparedList:
     """A list of tensors bound to one FastQuant plan: input pointers, output tensors and the descriptor array are set up
-    once; run() is ONE ctypes call (bfpq_fake_quantize_batched) whatever the number of tensors.  The inputs must keep their
-    storage (and stay contiguous) between runs; results are written in place into .outputs."""
+    once; run() is ONE ctypes call (bfpq_fake_quantize_batched) whatever the number of tensors.  The inputs are expected to
+    keep their storage between runs (a model's weights); run() checks every bound pointer against the tensor's current one
+    and re-binds a tensor whose storage moved (`model.to(...)`, `p.data = ...`, `load_state_dict(assign=True)`) -- a changed
+    dtype, device or element count raises instead of reading freed memory.  Results are written in place into .outputs."""
 
     def __init__(self, fq, tensors, apply_nm=None, outs=None):
         tensors = list(tensors)
@@ -389,12 +392,26 @@ class PreparedList:
             d.in_dev, d.out_dev, d.rows, d.cols, d.apply_nm = t.data_ptr(), dst.data_ptr(), t.numel() // cols, cols, 1 if flags[i] else 0
             self._k += 1
             self._keep.append(t)
+        self._bound = [(t, t.data_ptr(), t.numel()) for t in self._keep]
         self._plan = fq._plan(self.dtype, self.device) if self._k else None
         self._fn = load_library().bfpq_fake_quantize_batched
         self._addr = ctypes.addressof(self._descs)
 
+    def _rebind(self):
+        """descriptor j reads self._keep[j]: follow tensors whose storage moved since they were bound"""
+        for j, (t, ptr, n) in enumerate(self._bound):
+            cur = t.data_ptr()
+            if cur == ptr:
+                continue
+            if t.dtype != self.dtype or t.device != self.device or t.numel() != n or not t.is_contiguous():
+                raise RuntimeError("PreparedList: a bound tensor changed dtype / device / size / layout since it was bound "
+                                   f"(was {n} x {self.dtype} on {self.device}, is {t.numel()} x {t.dtype} on {t.device}); build a new list")
+            self._descs[j].in_dev = cur
+            self._bound[j] = (t, cur, n)
+
     def run(self):
         if self._k:
+            self._rebind()
             dev = self.device
             if torch.cuda.current_device() != dev.index:
                 with torch.cuda.device(dev):
@@ -408,9 +425,10 @@ class PreparedList:
 
 
 class SelectWorkspace:
-    """Device scratch of the unstructured path (include/bfpq.h: ws_dev): bfpq_select_state, the histogram buffers of the
-    single-device launches (cleared by the apply launch of the same call), and the tie bookkeeping.  One per (device, stream): the launches of
-    one call communicate through it."""
+    """Device scratch of the unstructured path (include/bfpq.h: ws_dev): bfpq_select_state, the ticket and coarse histogram of
+    the one-launch selection (16-bit dtypes; left zero by its last workgroup), the histogram buffers of the fp32 launch pairs
+    (cleared by the apply launch of the same call), and the tie bookkeeping.  One per (device, stream): the launches of one
+    call communicate through it."""
 
     def __init__(self, device):
         self.device = device
@@ -428,13 +446,15 @@ class SelectWorkspace:
         """host copy of bfpq_select_state (synchronises; for tests / diagnostics only)"""
         import struct
         raw = self.ws[:SELECT_STATE_BYTES // 8].cpu().numpy().tobytes()
-        prefix, mask, k_rem, tau, done, need, ties, k, tie_base, flags = struct.unpack_from("<IIqIIqqqqI", raw, 0)
+        prefix, mask, k_rem, tau, done, need, ties, k, tie_base, flags, cut_lo, cut_hi, cut_within = struct.unpack_from("<IIqIIqqqqIIII", raw, 0)
         return dict(prefix=prefix, prefix_mask=mask, k_rem=k_rem, tau=tau, done=done, need=need, ties=ties, k=k,
-                    tie_base=tie_base, flags=flags)
+                    tie_base=tie_base, flags=flags, cut_lo=cut_lo, cut_hi=cut_hi, cut_within=cut_within)
 
 
 def select_threshold(t, k, ws, numel_global=None, allgather=None):
     """radix-select the k-th smallest magnitude of t (device tensor) and leave threshold + tie bookkeeping in ws.
+    Single device: bfpq_select -- ONE launch for a 16-bit dtype (the histogram launch's last workgroup resolves), three
+    launch pairs for fp32.
     Multi-GPU: t is this rank's slab, k / numel_global are global, and allgather(hist) -> (hist_all [R, entries], R, rank)
     gathers the per-rank histograms (the one exchange of the path; an empty slab still joins it)."""
     require_device_tensor(t)
@@ -446,14 +466,16 @@ def select_threshold(t, k, ws, numel_global=None, allgather=None):
     null = ctypes.c_void_p(0)
     with torch.cuda.device(src.device):
         st = _stream(src)
-        if allgather is None and ws.dirty:                 # the previous select was never applied (diagnostic use)
+        if ws.dirty:                                       # the previous fp32 select was never applied (diagnostic use)
             check(L.bfpq_select_reset(_ptr(ws.ws), st), "bfpq_select_reset")
-        ws.dirty = allgather is None
+            ws.dirty = False
+        if allgather is None:
+            if ng != n:
+                raise ValueError("select_threshold: numel_global without an allgather")
+            check(L.bfpq_select(_ptr(src), n, code, int(k), _ptr(ws.ws), st), "bfpq_select")
+            ws.dirty = code == F32                         # (its histograms inside ws are cleared by the apply launch)
+            return
         for p in range(L.bfpq_select_passes(code)):
-            if allgather is None:
-                check(L.bfpq_select_hist(_ptr(src), n, code, p, int(k), ng, _ptr(ws.ws), null, st), "bfpq_select_hist")
-                check(L.bfpq_select_resolve(_ptr(src), n, code, p, int(k), null, 1, 0, _ptr(ws.ws), null, st), "bfpq_select_resolve")
-                continue
             hist = ws.ext_hist()                           # zero on entry: resolve clears it again after the gather
             check(L.bfpq_select_hist(_ptr(src) if n else null, n, code, p, int(k), ng, _ptr(ws.ws), _ptr(hist), st), "bfpq_select_hist")
             hist_all, R, rank = allgather(hist)
@@ -697,20 +719,41 @@ SPLIT_K = True            # False: never split K (A/B measurements)
 SHARE_ACT_IMAGE = True    # False: every call quantizes its activation (single-layer benchmarks that re-use one input tensor)
 
 
+def tensor_version(t):
+    """in-place version counter of a tensor, or None where it has none (tensors created under torch.inference_mode())"""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
 def _shared_image(x2, mant_bits, epsilon):
     """quantize_mx8 with a one-entry memo per device: the projections that share an input (q/k/v, gate/up) quantize it once.
     The entry holds the tensor it was made from, so that tensor's memory cannot be handed to another tensor while the entry
-    lives; the key includes the in-place version counter."""
-    key = (x2.data_ptr(), x2._version, tuple(x2.shape), tuple(x2.stride()), x2.dtype, int(mant_bits), float(epsilon),
-           torch.cuda.current_stream(x2.device).cuda_stream)
-    if not SHARE_ACT_IMAGE:
+    lives; the key includes the in-place version counter.  The memo is bypassed -- the image is made afresh and nothing is
+    stored -- whenever the key cannot vouch for the bytes: while a hipGraph is being captured (the launch is recorded, not
+    run: an entry made then would hold an image that was never computed), for inference-mode tensors (no version counter),
+    and with SHARE_ACT_IMAGE off.  Writes the version counter does not see (`.data` assignments, raw-pointer writes such as
+    this library's own `out=` arguments) are outside what the key can detect: callers that mutate an activation that way
+    between two projections must call forget_shared_images() (PackedBFP.linear and the cached BFPLinear never do)."""
+    if not SHARE_ACT_IMAGE or torch.cuda.is_current_stream_capturing():
         return quantize_mx8(x2, mant_bits, epsilon)
+    ver = None if x2.is_inference() else tensor_version(x2)
+    if ver is None:
+        return quantize_mx8(x2, mant_bits, epsilon)
+    key = (x2.data_ptr(), ver, tuple(x2.shape), tuple(x2.stride()), x2.dtype, int(mant_bits), float(epsilon),
+           torch.cuda.current_stream(x2.device).cuda_stream)
     hit = _last_image.get(x2.device)
     if hit is not None and hit[0] == key:
         return hit[2]
     img = quantize_mx8(x2, mant_bits, epsilon)
     _last_image[x2.device] = (key, x2, img)
     return img
+
+
+def forget_shared_images():
+    """drop the per-device activation-image memo (and the activation each entry keeps alive)"""
+    _last_image.clear()
 
 
 def hbfp_linear_mx8_ok(T, N, K, w_mant_bits, x_mant_bits, block_size=64):

@@ -77,22 +77,34 @@ int main()
         HIP(hipMalloc(&d_state, BFPQ_SELECT_WS_BYTES));
         HIP(hipMemset(d_state, 0, BFPQ_SELECT_WS_BYTES));
         const int64_t k = (int64_t)((double)n * 0.5);
-        for (int p = 0; p < bfpq_select_passes(BFPQ_BF16); p++) {       // single device: the workspace's own histogram buffers
-            RC(bfpq_select_hist(d_in, n, BFPQ_BF16, p, k, n, d_state, nullptr, s));
-            RC(bfpq_select_resolve(d_in, n, BFPQ_BF16, p, k, nullptr, 1, 0, d_state, nullptr, s));
-        }
-        RC(bfpq_threshold_apply(d_in, d_out, n, BFPQ_BF16, d_state, s));
-        HIP(hipStreamSynchronize(s));
-        bfpq_select_state st; HIP(hipMemcpy(&st, d_state, sizeof st, hipMemcpyDeviceToHost));
-        HIP(hipMemcpy(h_out.data(), d_out, n * 2, hipMemcpyDeviceToHost));
         float tau; int64_t kk;
         if (oracle_unstructured_sparsify(h_in.data(), h_ref.data(), n, BFPQ_BF16, 0.5, &tau, &kk)) return 5;
         uint32_t tb; memcpy(&tb, &tau, 4);
+        bfpq_select_state st;
         int64_t zeros = 0, zref = 0, diff_outside = 0;
-        for (int64_t i = 0; i < n; i++) {
-            zeros += (h_out[i] & 0x7fff) == 0; zref += (h_ref[i] & 0x7fff) == 0;
-            if ((uint32_t)(h_in[i] & 0x7fff) != (tb >> 16)) diff_outside += h_out[i] != h_ref[i];
+        std::vector<uint16_t> h_first;
+        bool same_both = true;
+        for (int form = 0; form < 2; form++) {              // 0: the one-launch selection; 1: the launch-pair form (what multi-GPU callers issue)
+            HIP(hipMemset(d_out, 0xff, n * 2));
+            if (form == 0) RC(bfpq_select(d_in, n, BFPQ_BF16, k, d_state, s));
+            else
+                for (int p = 0; p < bfpq_select_passes(BFPQ_BF16); p++) {       // single device: the workspace's own histogram buffers
+                    RC(bfpq_select_hist(d_in, n, BFPQ_BF16, p, k, n, d_state, nullptr, s));
+                    RC(bfpq_select_resolve(d_in, n, BFPQ_BF16, p, k, nullptr, 1, 0, d_state, nullptr, s));
+                }
+            RC(bfpq_threshold_apply(d_in, d_out, n, BFPQ_BF16, d_state, s));
+            HIP(hipStreamSynchronize(s));
+            HIP(hipMemcpy(&st, d_state, sizeof st, hipMemcpyDeviceToHost));
+            HIP(hipMemcpy(h_out.data(), d_out, n * 2, hipMemcpyDeviceToHost));
+            if (form == 0) h_first = h_out; else same_both = h_first == h_out;
+            zeros = zref = diff_outside = 0;
+            for (int64_t i = 0; i < n; i++) {
+                zeros += (h_out[i] & 0x7fff) == 0; zref += (h_ref[i] & 0x7fff) == 0;
+                if ((uint32_t)(h_in[i] & 0x7fff) != (tb >> 16)) diff_outside += h_out[i] != h_ref[i];
+            }
+            if (!(st.tau == (tb >> 16) && st.k == kk && zeros == zref && diff_outside == 0 && st.done == 1)) break;
         }
+        fails += !same_both;
         const bool ok = st.tau == (tb >> 16) && st.k == kk && zeros == zref && diff_outside == 0 && st.done == 1;
         printf("unstructured 50%% : tau 0x%x (oracle 0x%x) zeros %lld (oracle %lld) outside-tie diffs %lld : %s\n", st.tau, tb >> 16,
                (long long)zeros, (long long)zref, (long long)diff_outside, ok ? "ok" : "MISMATCH");

@@ -293,6 +293,7 @@ def main():
 
     write_g9(ops)
     write_g10()
+    write_g11(ops)
     tot = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print("golden fixtures written, total bytes:", tot, "torch", torch.__version__)
 
@@ -342,6 +343,15 @@ def write_g10():
         params = [torch.nn.Parameter(torch.randn(64, 128, generator=gen) * 0.05), torch.nn.Parameter(torch.randn(96, generator=gen) * 0.05)]
         opt = optm.BFPAdam(params, lr=1e-2, amsgrad=amsgrad)
         opt.bfp_args = cfg(mant_bits=7, weight_mant_bits=15, block_size=32)          # the YAML on disk says device 'cuda' / 'stoc'
+        # the parameters as they enter the snap (bfp_optim_lstm.py:85: the argument of float_to_bfp_blocked), recorded by a
+        # pass-through wrapper around the reference's own function: lets a test pin the snap alone, bit for bit
+        presnap = []
+        real_q = optm.float_to_bfp_blocked
+
+        def recording_q(t, *a, **kw):
+            presnap.append(t.detach().clone())
+            return real_q(t, *a, **kw)
+        optm.float_to_bfp_blocked = recording_q
         for i, p_ in enumerate(params):
             g10[f"{tag}_p{i}_init"] = bits(p_.data)
         for step in range(3):
@@ -349,14 +359,72 @@ def write_g10():
                 gr = torch.randn(p_.shape, generator=gen) * 0.1
                 g10[f"{tag}_g{i}_s{step}"] = bits(gr)
                 p_.grad = gr
+            del presnap[:]
             opt.step()
+            assert len(presnap) == len(params)
             for i, p_ in enumerate(params):
                 g10[f"{tag}_p{i}_s{step}"] = bits(p_.data)
+                g10[f"{tag}_pre{i}_s{step}"] = bits(presnap[i])
+        optm.float_to_bfp_blocked = real_q
     np.savez_compressed(os.path.join(HERE, "g10_bfpadam.npz"), **g10)
 
 
+def write_g11(ops):
+    """G11: the module / functional wrappers that the patched models call (bfp_ops.py:233-268), forward AND backward, captured
+    from the reference's own classes: BFPConv2d in 'bfp' mode (ViT's patch embedding, modeling_vit.py:168-173), the callable
+    of F_matmul_bfp (transpose path inside an autograd graph) and the callable of F_linear_bfp"""
+    g11 = {}
+    gen = torch.Generator().manual_seed(4711)
+    kw = cfg(mant_bits=7, block_size=16, N=1, M=4, w_sparsity=True, sparsity_mode='structured')     # BASELINE config 5's numerics
+    for dname in ("f32", "bf16"):
+        dt = DT[dname]
+        # (a) BFPConv2d(3, 64, 16, stride=16) on [2,3,32,32]
+        conv = ops.BFPConv2d(3, 64, 16, stride=16, **dict(kw))
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(64, 3, 16, 16, generator=gen) * 0.05)
+            conv.bias.copy_(torch.randn(64, generator=gen) * 0.01)
+        conv = conv.to(dt)
+        x = torch.randn(2, 3, 32, 32, generator=gen).to(dt).requires_grad_(True)
+        y = conv(x)
+        gy = torch.randn(y.shape, generator=gen).to(dt)
+        y.backward(gy)
+        for name, t in (("w", conv.weight.detach()), ("b", conv.bias.detach()), ("x", x.detach()), ("y", y.detach()), ("gy", gy),
+                        ("gx", x.grad), ("gw", conv.weight.grad), ("gb", conv.bias.grad),
+                        ("xq", ops.float_to_bfp_blocked(x.detach(), **kw, identifier='in')),
+                        ("wq", ops.float_to_bfp_blocked(conv.weight.detach(), **kw, identifier='w')),
+                        ("gq", ops.float_to_bfp_blocked(gy, **kw, identifier='grad'))):
+            g11[f"conv_{name}_{dname}"] = bits(t)
+        # (b) the callable of F_matmul_bfp on [2,4,16,32] x [2,4,32,16]
+        mm = ops.F_matmul_bfp(**dict(kw))
+        a = torch.randn(2, 4, 16, 32, generator=gen).to(dt).requires_grad_(True)
+        b = torch.randn(2, 4, 32, 16, generator=gen).to(dt).requires_grad_(True)
+        y = mm(a, b)
+        gy = torch.randn(y.shape, generator=gen).to(dt)
+        y.backward(gy)
+        aq, bq = ops.MxM_pre_processing(a.detach(), b.detach(), True, **kw)
+        for name, t in (("a", a.detach()), ("b", b.detach()), ("y", y.detach()), ("gy", gy), ("ga", a.grad), ("gb", b.grad),
+                        ("aq", aq), ("bq", bq.contiguous()), ("gq", ops.float_to_bfp_blocked(gy, **kw, identifier='grad'))):
+            g11[f"mm_{name}_{dname}"] = bits(t)
+        # (c) the callable of F_linear_bfp
+        fl = ops.F_linear_bfp(**dict(kw))
+        x = torch.randn(2, 5, 64, generator=gen).to(dt).requires_grad_(True)
+        w = (torch.randn(48, 64, generator=gen) * 0.05).to(dt).requires_grad_(True)
+        bias = (torch.randn(48, generator=gen) * 0.01).to(dt).requires_grad_(True)
+        y = fl(x, w, bias)
+        gy = torch.randn(y.shape, generator=gen).to(dt)
+        y.backward(gy)
+        for name, t in (("x", x.detach()), ("w", w.detach()), ("b", bias.detach()), ("y", y.detach()), ("gy", gy),
+                        ("gx", x.grad), ("gw", w.grad), ("gb", bias.grad)):
+            g11[f"lin_{name}_{dname}"] = bits(t)
+    # the non-'bfp' format returns the plain functions themselves (bfp_ops.py:237-238, :244-245)
+    assert ops.F_linear_bfp(num_format='fp32') is torch.nn.functional.linear and ops.F_matmul_bfp(num_format='fp32') is torch.matmul
+    np.savez_compressed(os.path.join(HERE, "g11_wrappers.npz"), **g11)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "g9":
+    if len(sys.argv) > 1 and sys.argv[1] == "g11":
+        write_g11(load_ref())
+    elif len(sys.argv) > 1 and sys.argv[1] == "g9":
         write_g9(load_ref())
     elif len(sys.argv) > 1 and sys.argv[1] == "g10":
         write_g10()

@@ -49,6 +49,34 @@ def test_bfpadam_config_errors():
     assert torch.isfinite(p[0]).all()
 
 
+@pytest.mark.parametrize("tag", ["plain", "ams"])
+def test_presnap_fixture_is_consistent_cpu(tag):
+    """the pre-snap parameters recorded from the reference (the argument of its float_to_bfp_blocked call, bfp_optim_lstm.py:85)
+    snap, through the oracle, to the reference's post-step parameters"""
+    g = load("g10_bfpadam.npz")
+    for step in range(3):
+        for i, shape in enumerate(((64, 128), (96,))):
+            pre = from_bits(g[f"{tag}_pre{i}_s{step}"], torch.float32).view(shape)
+            want = g[f"{tag}_p{i}_s{step}"].reshape(-1)
+            assert np.array_equal(bits(O.float_to_bfp_blocked(pre, **cfg(), sgd_update=True)).reshape(-1), want), (tag, step, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["plain", "ams"])
+def test_bfpadam_snap_is_bit_exact_on_the_gpu(tag):
+    """the HBFP16 snap alone (weight_mant_bits = 15, block 32, identifier '', sgd_update=True), on the parameters exactly as the
+    reference's optimizer handed them to its quantizer: the engine's result equals the reference's post-step parameters bit
+    for bit -- Adam's own arithmetic (torch's, on other hardware) is out of the picture"""
+    from quantization_sparsity_interplay_amd.bfp import bfp_ops
+    g = load("g10_bfpadam.npz")
+    for step in range(3):
+        for i, shape in enumerate(((64, 128), (96,))):
+            pre = from_bits(g[f"{tag}_pre{i}_s{step}"], torch.float32).view(shape).to("cuda:0")
+            got = bfp_ops.float_to_bfp_blocked(pre, **cfg(), sgd_update=True)
+            assert got.shape == pre.shape and got.dtype == torch.float32
+            assert np.array_equal(bits(got).reshape(-1), g[f"{tag}_p{i}_s{step}"].reshape(-1)), (tag, step, i)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag,amsgrad", [("plain", False), ("ams", True)])
 def test_bfpadam_gpu(tag, amsgrad):

@@ -35,7 +35,7 @@ def synth(rows, cols, dtype, scale=0.02, seed=1234):
 
 def test_native_library_is_the_one_running():
     assert torch.cuda.is_available()
-    assert pkg.load_library().bfpq_version() == 2
+    assert pkg.load_library().bfpq_version() == 3
     import os
     maps = open(f"/proc/{os.getpid()}/maps").read()
     assert "libbfpq.so" in maps
