@@ -106,26 +106,44 @@ def _no_sparsity_float_to_bfp(t, block_size, mant_bits, epsilon, rounding_mode, 
 
 
 _select_ws = collections.OrderedDict()
+_spare_ws = {}                     # device index -> workspaces made (and really zeroed) outside any capture, for streams first met inside one
 _SELECT_WS_MAX = 16                # workspaces kept (5 MB each): least recently used (device, stream) pairs beyond that are dropped
+_SPARES = 2
 
 
 def _workspace(device):
     """select workspace of the current stream of `device` (the launches of one call talk through it, so two streams
-    must not share one).  Kept per (device, stream), least recently used first out.  A workspace cannot be born inside a
-    hipGraph capture -- its zero-fill would be recorded instead of run and its memory would belong to the graph's pool -- so
-    the first unstructured call on a stream has to happen outside capture (a warm-up call, as capture needs anyway)."""
+    must not share one).  Kept per (device, stream), least recently used first out -- except workspaces a captured graph
+    refers to, which stay for good (the graph holds their address).
+    A workspace cannot be BORN inside a hipGraph capture: its zero-fill would be recorded instead of run, and its memory would
+    belong to the graph's pool.  torch.cuda.graph() captures on a stream of its own, so a stream first met inside a capture
+    gets one of the spare workspaces that every eager call keeps in stock; only a capture with no eager unstructured call
+    before it on this device (capture needs a warm-up anyway) finds none."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    capturing = torch.cuda.is_current_stream_capturing()
     ws = _select_ws.get(key)
     if ws is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("the unstructured path needs its per-stream workspace before graph capture starts: "
-                               "run the call once on this stream outside torch.cuda.graph(...) first")
-        ws = _select_ws[key] = native.SelectWorkspace(torch.device("cuda", idx))
-        while len(_select_ws) > _SELECT_WS_MAX:
-            _select_ws.popitem(last=False)
+        if capturing:
+            spares = _spare_ws.get(idx)
+            if not spares:
+                raise RuntimeError("the unstructured path needs a workspace that exists before graph capture starts: "
+                                   "run one unstructured call on this device outside torch.cuda.graph(...) first (outside the capture)")
+            ws = spares.pop()
+        else:
+            ws = native.SelectWorkspace(torch.device("cuda", idx))
+        _select_ws[key] = ws
+        if len(_select_ws) > _SELECT_WS_MAX:
+            for old in [k for k, w in _select_ws.items() if not w.pinned and k != key][:len(_select_ws) - _SELECT_WS_MAX]:
+                del _select_ws[old]
     else:
         _select_ws.move_to_end(key)
+    if capturing:
+        ws.pinned = True
+    else:
+        spares = _spare_ws.setdefault(idx, [])
+        while len(spares) < _SPARES:
+            spares.append(native.SelectWorkspace(torch.device("cuda", idx)))
     return ws
 
 
@@ -225,6 +243,9 @@ def float_to_bfp_blocked(t, mant_bits, epsilon, rounding_mode, device, block_siz
             raise RuntimeError("selected index k out of range")
         mb = weight_mant_bits if sgd_update else mant_bits
         ws = _workspace(t.device)
+        if rounding_mode == rounding_modes.DETERM:
+            # one entry point: the resident one-read kernel where it applies, else selection launch + fused apply launch
+            return native.prune_quantize(t, k, ws, block_size, mb, epsilon).view(t.shape)
         native.select_threshold(t, k, ws)
         y, _, _ = native.quantize_threshold(t, ws, block_size, mb, epsilon, stoch_seed=_seed_for(rounding_mode))
         return _stoc_dtype(y.view(t.shape), rounding_mode)

@@ -1,0 +1,236 @@
+// bfpq_select.h -- device code shared by the launches that select the global magnitude threshold (bfpq_unstructured.hip: the
+// histogram launch; bfpq_fused.h: the resident prune + quantize kernel): publishing a segment's counts, the ticket, and the
+// resolve step that the last workgroup runs.  Reference: src/transformers/bfp/bfp_ops.py:61-71.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "bfpq.h"
+#include "bfpq_common.h"
+#include "bfpq_device.h"
+
+namespace bfpq_dev {
+
+// Build with EXTRA=-DBFPQ_STAMPS for phase timing (tools_dev/stamps.py): thread 0 of every workgroup records the
+// constant 100 MHz clock at named points; never in the product build.
+#ifdef BFPQ_STAMPS
+static __device__ unsigned long long bfpq_g_stamps[3][512][8];        // (one copy per translation unit, read back by that unit's bfpq_debug_stamps*)
+#define STAMP(kern, idx) do { if (threadIdx.x == 0 && blockIdx.x < 512) { unsigned long long t_; \
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); bfpq_g_stamps[kern][blockIdx.x][idx] = t_; } } while (0)
+#else
+#define STAMP(kern, idx) do { } while (0)
+#endif
+
+// words that one workgroup hands to another INSIDE a launch (segment windows -> the resolving workgroup) travel as
+// agent-scope relaxed atomics: write-through stores, cache-bypassing loads, no fences (cdna_hip_programming.md, guideline 16 R1)
+__device__ __forceinline__ void pub_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t pub_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// After the streaming loop and a barrier (the LDS histogram of the segment is complete; 15-bit keys, 1024 threads): publish the
+// segment -- its 256 coarse sums into one of the workspace's coarse-histogram copies, a 2048-bin window of the fine histogram
+// around the segment's own k-quantile, and the window's position -- then draw the ticket.  True for the LAST workgroup of
+// the grid: everything every segment published is in memory when it returns.  s_coarse: 256 words, 16-byte aligned;
+// s_res: 4 words.  Nobody waits for anybody here.
+__device__ __forceinline__ bool seg_publish_and_ticket(const uint32_t* s_hist, uint32_t* s_coarse, uint32_t* s_res, SelWs* ws,
+                                                       int64_t k, int64_t numel_global)
+{
+    const int t = threadIdx.x;
+    const int copy = blockIdx.x % BFPQ_SELECT_HIST_COPIES;
+    {
+        // coarse histogram (256 bins of 128): four threads per coarse bin, each sums 32 bins with 16-byte LDS reads in a
+        // rotated order (two lanes per bank), then a quad reduction
+        const int q = t >> 2, r = t & 3;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint4 c4 = *reinterpret_cast<const uint4*>(&s_hist[q * 128 + ((j + q) & 7) * 16 + r * 4]);
+            sum += c4.x + c4.y + c4.z + c4.w;
+        }
+        sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+        sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+        if (r == 0) { s_coarse[q] = sum; if (sum) atomicAdd(&ws->coarse[copy][q], sum); }
+    }
+    __syncthreads();
+    STAMP(0, 3);
+    // window: the 16 coarse bins (2048 bins) around the one that holds the segment's own k-quantile (first wave: four coarse
+    // sums per lane, one wave scan)
+    if (t < 64) {
+        const uint4 c4 = *reinterpret_cast<const uint4*>(&s_coarse[t * 4]);
+        const uint32_t mine = c4.x + c4.y + c4.z + c4.w;
+        const uint32_t incl = wave_incl_scan(mine);
+        const uint32_t seg_elems = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint64_t target = numel_global > 0 ? (uint64_t)((double)seg_elems * ((double)k / (double)numel_global)) : 0ull;   // (an anchor, not a count)
+        if (seg_elems && target >= seg_elems) target = seg_elems - 1;
+        const uint32_t excl = incl - mine;
+        if (t == 0) s_res[0] = 0;
+        if (mine && excl <= target && target < (uint64_t)excl + mine) {
+            uint32_t e = excl;
+            int A = t * 4;
+            if (target >= e + c4.x) { e += c4.x; A++; if (target >= e + c4.y) { e += c4.y; A++; if (target >= e + c4.z) A++; } }
+            int clo = A - kWinBins / 256;
+            clo = clo < 0 ? 0 : (clo > kCoarseBins - kWinBins / 128 ? kCoarseBins - kWinBins / 128 : clo);
+            uint32_t inside = 0;
+            for (int j = 0; j < kWinBins / 128; j++) inside += s_coarse[clo + j];
+            s_res[0] = (uint32_t)clo * 128u;
+            pub_store(&ws->seg_win[blockIdx.x], ((uint32_t)clo * 128u) | (inside != seg_elems ? 0x80000000u : 0u));
+        }
+        if (seg_elems == 0 && t == 0) pub_store(&ws->seg_win[blockIdx.x], 0u);          // (an empty segment: no window, nothing outside it)
+    }
+    __syncthreads();
+    STAMP(0, 4);
+    const int lo = (int)s_res[0];
+    pub_store(&ws->windows[blockIdx.x][t], s_hist[lo + t]);
+    pub_store(&ws->windows[blockIdx.x][kSelThreads + t], s_hist[lo + kSelThreads + t]);
+    STAMP(0, 5);
+    // publish: every storing wave drains, the workgroup meets, one lane draws the ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) s_res[1] = __hip_atomic_fetch_add(&ws->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)gridDim.x - 1u ? 1u : 0u;
+    __syncthreads();
+    return s_res[1] != 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The resolve step inside the histogram launch (single device, 16-bit dtypes): run by the LAST workgroup to draw its ticket,
+// i.e. when every segment's coarse counts and window are in memory.  1024 threads; lds: the (finished) histogram's LDS.
+//   coarse bins (8 copies) -> scan -> the coarse bin C that holds the k-th key
+//   every segment's window slice for C (one agent-scope load per segment and fine bin, 32 per thread, all independent)
+//     -> their sum is the global fine histogram of C -> scan -> tau; the column of tau is every segment's tie count
+//     -> scan -> the cut segment
+// A segment whose window does not cover C although it has magnitudes outside its window is counted again here (one
+// workgroup: slow, correct, and only for tensors whose segments live on wildly different scales).
+// ---------------------------------------------------------------------------------------------
+template <int DT, bool FAST>
+__device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int64_t n_items, const SegGeom g, int64_t k, SelWs* ws, uint32_t* lds, bool publish)
+{
+    constexpr int VEC = Traits<DT>::VEC;
+    constexpr int NC = BFPQ_SELECT_HIST_COPIES;
+    // ONE compute unit runs this while the rest of the chip idles: every instruction counts.  No branches around the loads:
+    // per segment one LDS word says where its slice for C lies (or that it has none), the 32 K slice words come as 16-byte
+    // cache-bypassing buffer loads, eight per thread, all in flight together.
+    uint32_t* s_off = lds;               // [256] word offset of the segment's slice inside ws->windows | bit 31: no slice
+    uint32_t* s_tc = lds + 256;          // [256]
+    uint32_t* s_fine = lds + 512;        // [32][128]
+    uint32_t* s_part = lds + 4608;       // [16]
+    uint32_t* s_r = lds + 4624;          // [16]
+    uint32_t* s_h = lds + 4640;          // [128]
+    uint32_t* s_segwin = lds + 4768;     // [256]
+    const int t = threadIdx.x;
+    STAMP(2, 0);
+    uint32_t cv = 0;
+    if (t < kCoarseBins) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) cv += pub_load(&ws->coarse[c][t]);
+    }
+    const uint32_t sw = t < g.G ? pub_load(&ws->seg_win[t]) : 0u;
+    __syncthreads();                                         // (the histogram's LDS is dead from here on)
+    if (t < kMaxSeg) s_segwin[t] = sw;
+    if (t < 16) s_r[t] = 0;
+    const uint32_t k_rem = (uint32_t)k;
+    uint32_t total;
+    uint32_t excl = block_excl_scan(cv, s_part, &total);     // (its barriers also order the resets above)
+    if (cv && excl < k_rem && k_rem <= excl + cv) { s_r[0] = (uint32_t)t; s_r[1] = excl; }
+    __syncthreads();
+    const uint32_t C = s_r[0], before = s_r[1];              // (k == 0: bin 0, nothing in front of it)
+    STAMP(2, 1);
+    for (int i = t; i < NC * kCoarseBins; i += kSelThreads) (&ws->coarse[0][0])[i] = 0u;     // zero for the next call
+    // segments whose window cannot answer for C
+    int miss = 0;
+    if (t < g.G) {
+        const uint32_t clo = (sw & 0x3fffffffu) >> 7;
+        if (!(C - clo < (uint32_t)(kWinBins / 128)) && (sw >> 31)) miss = 1;
+    }
+    if (__syncthreads_or(miss)) {
+        if (t < kMaxSeg) s_tc[t] = (uint32_t)miss;
+        __syncthreads();
+        for (int s = 0; s < g.G; s++) {
+            if (!s_tc[s]) continue;                          // (block-uniform)
+            if (t < 128) s_h[t] = 0;
+            __syncthreads();
+            const int64_t i0 = (int64_t)s * g.L, i1 = i0 + g.L < n_items ? i0 + g.L : n_items;
+            for (int64_t it = i0 + t; it < i1; it += kSelThreads) {
+                uint32_t r[VEC];
+                sweep_load<DT, FAST>(in, it, n_items, numel, r);
+#pragma unroll
+                for (int j = 0; j < VEC; j++) {
+                    const uint32_t key = mag_key<DT>(r[j]);
+                    if ((FAST || it * VEC + j < numel) && (key >> 7) == C) atomicAdd(&s_h[key & 127u], 1u);
+                }
+            }
+            __syncthreads();
+            if (t < 128) pub_store(&ws->windows[s][t], s_h[t]);
+            if (t == 0) s_segwin[s] = (C << 7) | (1u << 30);                 // a 128-bin window at C
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    if (t < kMaxSeg) {
+        uint32_t off = 0x80000000u;
+        if (t < g.G) {
+            const uint32_t w = s_segwin[t], clo = (w & 0x3fffffffu) >> 7;
+            const bool narrow = (w >> 30) & 1u;
+            if (narrow ? clo == C : C - clo < (uint32_t)(kWinBins / 128)) off = (uint32_t)t * kWinBins + (narrow ? 0u : (C - clo) * 128u);
+        }
+        s_off[t] = off;
+    }
+    __syncthreads();
+    STAMP(2, 2);
+    // window slices: thread (sg, q) reads the fine bins 4q..4q+3 of C from the segments sg, sg + 32, ...
+    typedef unsigned int v4u __attribute__((vector_size(16)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(&ws->windows[0][0], 0, (int)sizeof(ws->windows), 0x00020000);
+    const int sg = t >> 5, q = t & 31;
+    v4u cnt[kMaxSeg / 32];
+    uint32_t offs[kMaxSeg / 32];
+#pragma unroll
+    for (int j = 0; j < kMaxSeg / 32; j++) offs[j] = s_off[sg + 32 * j];
+#pragma unroll
+    for (int j = 0; j < kMaxSeg / 32; j++)
+        cnt[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((offs[j] & 0x7fffffffu) + 4u * (uint32_t)q) * 4u), 0, 16 /* sc1: past this CU's caches */);
+    v4u sum = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < kMaxSeg / 32; j++) {
+        if (offs[j] >> 31) cnt[j] = (v4u){0u, 0u, 0u, 0u};
+        sum += cnt[j];
+    }
+    *reinterpret_cast<v4u*>(&s_fine[sg * 128 + 4 * q]) = sum;
+    __syncthreads();
+    STAMP(2, 3);
+    uint32_t fv = 0;
+    if (t < 128) {
+#pragma unroll
+        for (int i = 0; i < 32; i++) fv += s_fine[i * 128 + t];
+    }
+    excl = before + block_excl_scan(fv, s_part, &total);
+    if (fv && excl < k_rem && k_rem <= excl + fv) { s_r[2] = (C << 7) + (uint32_t)t; s_r[3] = excl; s_r[4] = fv; }
+    __syncthreads();
+    const uint32_t tau = s_r[2], run = s_r[3], ties = s_r[4];
+    const uint32_t need = k_rem - run;
+    STAMP(2, 4);
+    // the column of tau: every segment's tie count
+    if (q == (int)((tau & 127u) >> 2)) {
+        const uint32_t comp = tau & 3u;
+#pragma unroll
+        for (int j = 0; j < kMaxSeg / 32; j++) s_tc[sg + 32 * j] = comp == 0 ? cnt[j][0] : (comp == 1 ? cnt[j][1] : (comp == 2 ? cnt[j][2] : cnt[j][3]));
+    }
+    __syncthreads();
+    const uint32_t tc = t < g.G ? s_tc[t] : 0u;
+    cut_from_seg_ties(tc, (int64_t)need, g, n_items, s_part, s_r + 8);
+    STAMP(2, 5);
+    if (t == 0) {
+        bfpq_select_state* st = &ws->st;
+        st->prefix = tau; st->prefix_mask = 0x7fffu; st->k_rem = (int64_t)need; st->tau = tau; st->done = 1;
+        st->need = (int64_t)need; st->ties = (int64_t)ties; st->k = k; st->tie_base = 0;
+        st->flags = 1u; st->cut_lo = s_r[8]; st->cut_hi = s_r[9]; st->cut_within = s_r[10];
+        st->reserved[0] = st->reserved[1] = 0;
+        ws->ticket = 0u;                                     // ready for the next call
+        if (publish) {
+            // the resident kernel's other workgroups are waiting for exactly these words: write-through stores, drained, then
+            // the epoch they poll
+            pub_store(&ws->res_pub[0], tau); pub_store(&ws->res_pub[1], k > 0 ? 1u : 0u);
+            pub_store(&ws->res_pub[2], s_r[8]); pub_store(&ws->res_pub[3], s_r[9]); pub_store(&ws->res_pub[4], s_r[10]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(&ws->epoch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+
+}  // namespace bfpq_dev

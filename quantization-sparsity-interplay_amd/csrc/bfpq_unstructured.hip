@@ -6,145 +6,18 @@
 #include "bfpq.h"
 #include "bfpq_common.h"
 #include "bfpq_device.h"
+#include "bfpq_select.h"
 
 using namespace bfpq;
 using namespace bfpq_dev;
 
 namespace {
 
-// Build with EXTRA=-DBFPQ_STAMPS for phase timing (tools_dev/stamps.py): thread 0 of every workgroup records the
-// constant 100 MHz clock at named points; never in the product build.
-#ifdef BFPQ_STAMPS
-__device__ unsigned long long g_stamps[3][512][8];
-#define STAMP(kern, idx) do { if (threadIdx.x == 0 && blockIdx.x < 512) { unsigned long long t_; \
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_stamps[kern][blockIdx.x][idx] = t_; } } while (0)
-#else
-#define STAMP(kern, idx) do { } while (0)
-#endif
-
-// words that one workgroup hands to another INSIDE a launch (segment windows -> the resolving workgroup) travel as
-// agent-scope relaxed atomics: write-through stores, cache-bypassing loads, no fences (cdna_hip_programming.md, guideline 16 R1)
-__device__ __forceinline__ void pub_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint32_t pub_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// ---------------------------------------------------------------------------------------------
-// The resolve step inside the histogram launch (single device, 16-bit dtypes): run by the LAST workgroup to draw its ticket,
-// i.e. when every segment's coarse counts and window are in memory.  1024 threads; lds: the (finished) histogram's LDS.
-//   coarse bins (8 copies) -> scan -> the coarse bin C that holds the k-th key
-//   every segment's window slice for C (one agent-scope load per segment and fine bin, 32 per thread, all independent)
-//     -> their sum is the global fine histogram of C -> scan -> tau; the column of tau is every segment's tie count
-//     -> scan -> the cut segment
-// A segment whose window does not cover C although it has magnitudes outside its window is counted again here (one
-// workgroup: slow, correct, and only for tensors whose segments live on wildly different scales).
-// ---------------------------------------------------------------------------------------------
-template <int DT, bool FAST>
-__device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int64_t n_items, const SegGeom g, int64_t k, SelWs* ws, uint32_t* lds)
-{
-    constexpr int VEC = Traits<DT>::VEC;
-    constexpr int NC = BFPQ_SELECT_HIST_COPIES;
-    uint32_t* s_segwin = lds;            // [256]
-    uint32_t* s_tc = lds + 256;          // [256]
-    uint32_t* s_fine = lds + 512;        // [8][128]
-    uint32_t* s_part = lds + 1536;       // [16]
-    uint32_t* s_r = lds + 1552;          // [16]
-    uint32_t* s_h = lds + 1568;          // [128]
-    const int t = threadIdx.x;
-    uint32_t cv = 0;
-    if (t < kCoarseBins) {
-#pragma unroll
-        for (int c = 0; c < NC; c++) cv += pub_load(&ws->coarse[c][t]);
-    }
-    const uint32_t sw = t < g.G ? pub_load(&ws->seg_win[t]) : 0u;
-    __syncthreads();                                         // (the histogram's LDS is dead from here on)
-    if (t < kMaxSeg) s_segwin[t] = sw;
-    if (t < 16) s_r[t] = 0;
-    const uint32_t k_rem = (uint32_t)k;
-    uint32_t total;
-    uint32_t excl = block_excl_scan(cv, s_part, &total);     // (its barriers also order the resets above)
-    if (cv && excl < k_rem && k_rem <= excl + cv) { s_r[0] = (uint32_t)t; s_r[1] = excl; }
-    __syncthreads();
-    const uint32_t C = s_r[0], before = s_r[1];              // (k == 0: bin 0, nothing in front of it)
-    for (int i = t; i < NC * kCoarseBins; i += kSelThreads) (&ws->coarse[0][0])[i] = 0u;     // zero for the next call
-    // segments whose window cannot answer for C
-    int miss = 0;
-    if (t < g.G) {
-        const uint32_t clo = (sw & 0x3fffffffu) >> 7;
-        if (!(C - clo < (uint32_t)(kWinBins / 128)) && (sw >> 31)) miss = 1;
-    }
-    if (__syncthreads_or(miss)) {
-        if (t < kMaxSeg) s_tc[t] = (uint32_t)miss;
-        __syncthreads();
-        for (int s = 0; s < g.G; s++) {
-            if (!s_tc[s]) continue;                          // (block-uniform)
-            if (t < 128) s_h[t] = 0;
-            __syncthreads();
-            const int64_t i0 = (int64_t)s * g.L, i1 = i0 + g.L < n_items ? i0 + g.L : n_items;
-            for (int64_t it = i0 + t; it < i1; it += kSelThreads) {
-                uint32_t r[VEC];
-                sweep_load<DT, FAST>(in, it, n_items, numel, r);
-#pragma unroll
-                for (int j = 0; j < VEC; j++) {
-                    const uint32_t key = mag_key<DT>(r[j]);
-                    if ((FAST || it * VEC + j < numel) && (key >> 7) == C) atomicAdd(&s_h[key & 127u], 1u);
-                }
-            }
-            __syncthreads();
-            if (t < 128) pub_store(&ws->windows[s][t], s_h[t]);
-            if (t == 0) s_segwin[s] = (C << 7) | (1u << 30);                 // a 128-bin window at C
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    }
-    // window slices: thread (sg, f) reads fine bin f of C from the segments sg, sg + 8, ...
-    const int sg = t >> 7, f = t & 127;
-    uint32_t cnt[kMaxSeg / 8], sum = 0;
-#pragma unroll
-    for (int j = 0; j < kMaxSeg / 8; j++) {
-        const int s = sg + 8 * j;
-        uint32_t v = 0;
-        if (s < g.G) {
-            const uint32_t w = s_segwin[s], clo = (w & 0x3fffffffu) >> 7;
-            const bool narrow = (w >> 30) & 1u;
-            if (narrow ? clo == C : C - clo < (uint32_t)(kWinBins / 128)) v = pub_load(&ws->windows[s][(narrow ? 0u : (C - clo) * 128u) + (uint32_t)f]);
-        }
-        cnt[j] = v;
-        sum += v;
-    }
-    s_fine[sg * 128 + f] = sum;
-    __syncthreads();
-    uint32_t fv = 0;
-    if (t < 128) {
-#pragma unroll
-        for (int q = 0; q < 8; q++) fv += s_fine[q * 128 + t];
-    }
-    excl = before + block_excl_scan(fv, s_part, &total);
-    if (fv && excl < k_rem && k_rem <= excl + fv) { s_r[2] = (C << 7) + (uint32_t)t; s_r[3] = excl; s_r[4] = fv; }
-    __syncthreads();
-    const uint32_t tau = s_r[2], run = s_r[3], ties = s_r[4];
-    const uint32_t need = k_rem - run;
-    // the column of tau: every segment's tie count
-    if (f == (int)(tau & 127u)) {
-#pragma unroll
-        for (int j = 0; j < kMaxSeg / 8; j++) s_tc[sg + 8 * j] = cnt[j];
-    }
-    __syncthreads();
-    const uint32_t tc = t < g.G ? s_tc[t] : 0u;
-    cut_from_seg_ties(tc, (int64_t)need, g, n_items, s_part, s_r + 8);
-    if (t == 0) {
-        bfpq_select_state* st = &ws->st;
-        st->prefix = tau; st->prefix_mask = 0x7fffu; st->k_rem = (int64_t)need; st->tau = tau; st->done = 1;
-        st->need = (int64_t)need; st->ties = (int64_t)ties; st->k = k; st->tie_base = 0;
-        st->flags = 1u; st->cut_lo = s_r[8]; st->cut_hi = s_r[9]; st->cut_within = s_r[10];
-        st->reserved[0] = st->reserved[1] = 0;
-        ws->ticket = 0u;                                     // ready for the next call
-    }
-}
-
 // Launch 1: histogram of the current digit.  One workgroup per flat-contiguous segment (see the block comment at ThrCtx);
 // LDS histogram (32 768 bins = 128 KB for 16-bit keys).  On the pass that decides the threshold the workgroup also leaves a
 // window of its private histogram in the workspace.
 //   fuse != 0 (single device, 16-bit dtypes): only the 256 coarse sums go to the global histogram; the workgroup publishes
-//     its window, draws a ticket, and the last one resolves the selection (fused_resolve) -- one launch.
+//     its window, draws a ticket, and the last one resolves the selection (bfpq_select.h) -- one launch.
 //   fuse == 0: the non-zero fine bins are flushed by integer atomics (deterministic) for the resolve launch.
 template <int DT, bool FAST>
 __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int64_t numel, int pass, int shift, int nbits, int first, int last,
@@ -205,6 +78,13 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
     STAMP(0, 1);
     __syncthreads();
     STAMP(0, 2);
+    if (fuse) {                                             // (host: only with nbits == 15, first and last pass in one)
+        if (!seg_publish_and_ticket(s_hist, s_coarse, s_res, ws, k, numel_global)) return;
+        STAMP(0, 6);
+        fused_resolve<DT, FAST>(in, numel, n_items, g, k, ws, s_hist, false);
+        STAMP(0, 7);
+        return;
+    }
     const int copy = blockIdx.x % BFPQ_SELECT_HIST_COPIES;
     hist += (size_t)copy * BFPQ_SELECT_HIST_ENTRIES;
     const bool windows = last && nbits == 15;
@@ -220,7 +100,7 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
         }
         sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
         sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
-        if (r == 0) { s_coarse[q] = sum; if (sum) atomicAdd(fuse ? &ws->coarse[copy][q] : &hist[kFineBins + q], sum); }
+        if (r == 0) { s_coarse[q] = sum; if (sum) atomicAdd(&hist[kFineBins + q], sum); }
         __syncthreads();
     }
     STAMP(0, 3);
@@ -250,8 +130,8 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
     }
     // flush of the non-zero bins by integer atomics (deterministic) into this workgroup's COPY of the histogram: with
     // all workgroups adding into one copy every hot address takes 256 serialised adds (~3 us behind the streaming loop).
-    // The LDS reads of a thread are issued together.  (Not in the fused launch: its resolve step sums the windows.)
-    if (nbits == 15 && !fuse) {
+    // The LDS reads of a thread are issued together.
+    if (nbits == 15) {
         // one coarse bin (128 fine bins, two 256-byte atomic wave-instructions) per wave and trip; the empty ones -- all but
         // 15-20 of the 256 for a weight tensor -- are skipped on their coarse sum
         const int lane = t & 63;
@@ -280,16 +160,6 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
     pub_store(&ws->windows[blockIdx.x][t], s_hist[lo + t]);
     pub_store(&ws->windows[blockIdx.x][kSelThreads + t], s_hist[lo + kSelThreads + t]);
     STAMP(0, 5);
-    if (!fuse) return;
-    // publish: every storing wave drains, the workgroup meets, one lane draws the ticket; the last workgroup resolves
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t == 0) s_res[1] = __hip_atomic_fetch_add(&ws->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)gridDim.x - 1u ? 1u : 0u;
-    __syncthreads();
-    if (!s_res[1]) return;
-    STAMP(0, 6);
-    fused_resolve<DT, FAST>(in, numel, n_items, g, k, ws, s_hist);
-    STAMP(0, 7);
 }
 
 // Launch 2 of the launch-pair form (multi-GPU: between them the all-gather of the histograms; fp32: three pairs): one
@@ -485,7 +355,7 @@ __global__ void __launch_bounds__(kThreads) k_threshold_apply(const void* in, vo
 extern "C" {
 
 #ifdef BFPQ_STAMPS
-int bfpq_debug_stamps(void* host_dst) { return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
+int bfpq_debug_stamps(void* host_dst) { return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(bfpq_g_stamps), sizeof(bfpq_g_stamps)); }
 #endif
 
 int bfpq_select_passes(int dtype) { return dtype == BFPQ_F32 ? 3 : 1; }
