@@ -49,7 +49,7 @@ int bfpq_version(void);
 #define BFPQ_TUNE_MAX_GRID 0       /* cap on workgroups of the streaming kernels (default 1024) */
 #define BFPQ_TUNE_GEMM_ROW_TILES 1 /* 16-row tiles per wave in bfpq_hbfp_linear_decode_tiled: 0 = choose (default), 1, 2, 4 */
 #define BFPQ_TUNE_MX8_VARIANT 2    /* tile shape of bfpq_hbfp_linear_mx8: -1 = choose (default), 0..6 force (A/B measurements) */
-#define BFPQ_TUNE_RESIDENT 3       /* bfpq_prune_quantize: 1 = use the resident one-read kernel where it applies (default), 0 = always the two launches */
+#define BFPQ_TUNE_RESIDENT 3       /* bfpq_prune_quantize: 1 = use the resident one-read kernel where it applies, 0 = always the two launches (default: measured faster) */
 #define BFPQ_TUNE_RESIDENT_TIMEOUT_US 4 /* how long a workgroup of the resident kernel waits for the resolved threshold (default 200000) */
 int bfpq_tune(int key, int value);
 const char* bfpq_error_string(int code);
@@ -163,7 +163,7 @@ int bfpq_nm_sparsify(const void* in_dev, void* out_dev, int64_t rows, int64_t co
 #define BFPQ_SELECT_WINDOW_BINS 2048
 #define BFPQ_SELECT_HIST_ENTRIES (32768 + 256)   /* fine bins, then (16-bit dtypes) 256 coarse bins of 128 */
 #define BFPQ_SELECT_HIST_COPIES 8                /* a device accumulates into 8 copies (cuts the contention of the flush) */
-#define BFPQ_SELECT_WS_BYTES (BFPQ_SELECT_STATE_BYTES + 4 * (12 + BFPQ_SELECT_HIST_COPIES * 256 + 3 * BFPQ_SELECT_HIST_COPIES * BFPQ_SELECT_HIST_ENTRIES + \
+#define BFPQ_SELECT_WS_BYTES (BFPQ_SELECT_STATE_BYTES + 4 * (44 + BFPQ_SELECT_HIST_COPIES * 256 + 3 * BFPQ_SELECT_HIST_COPIES * BFPQ_SELECT_HIST_ENTRIES + \
                               2 * BFPQ_SELECT_MAX_SEGMENTS + BFPQ_SELECT_MAX_SEGMENTS * BFPQ_SELECT_WINDOW_BINS))
 
 int bfpq_select_passes(int dtype);
@@ -198,6 +198,16 @@ int bfpq_quantize_threshold(const void* in_dev, void* out_deq_dev, void* out_cod
  * Same result either way. */
 int bfpq_prune_quantize(const void* in_dev, void* out_dev, int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits,
                         double epsilon, int64_t k, const uint8_t* exp_win_dev, void* ws_dev, void* stream);
+/* The same op for a LIST of tensors -- every Linear weight of a model (BASELINE config 4) -- pipelined over two streams: the
+ * selection launch of tensor i + 1 runs on `stream` while the prune + quantize launch of tensor i runs on `aux_stream`, so the
+ * selection's serial tail (publishing, the ticket, the resolve step: ~10 us in which the memory system idles) is covered by the
+ * other tensor's streaming.  ws_devs: n_ws >= 2 caller-owned workspaces (BFPQ_SELECT_WS_BYTES each, zeroed once), used in
+ * rotation; events order their reuse.  aux_stream == NULL (or n_ws < 2): everything on `stream`, tensor by tensor.
+ * On return `stream` waits for everything issued on aux_stream (fork / join: hipGraph-capturable from `stream`).
+ * Creates and destroys a handful of hipEvents per call; launches only, no synchronisation. */
+typedef struct bfpq_prune_desc { const void* in_dev; void* out_dev; int64_t rows, cols; int64_t k; } bfpq_prune_desc;
+int bfpq_prune_quantize_batched(const bfpq_prune_desc* descs_host, int n, int dtype, int block_size, int mant_bits, double epsilon,
+                                const uint8_t* exp_win_dev, void* const* ws_devs_host, int n_ws, void* stream, void* aux_stream);
 /* 1 if bfpq_prune_quantize would take the resident kernel for this problem on the current device */
 int bfpq_prune_quantize_is_resident(const void* in_dev, void* out_dev, int64_t rows, int64_t cols, int dtype, int block_size);
 /* reads (synchronising the stream) and clears the error word of a workspace: non-zero if a resident launch gave up waiting */

@@ -259,13 +259,40 @@ def float_to_bfp_blocked(t, mant_bits, epsilon, rounding_mode, device, block_siz
 
 
 # ---- additive public surface (no counterpart in the reference) -------------------------------
+def _unstructured_lean(a, sparsity, sgd_update=False):
+    """the configuration is the s-first unstructured drop-in op (prune int(numel * frac) elements, then HBFP, round-half-even)"""
+    return (sparsity and a['num_format'] == 'bfp' and a['sparsity_num_format'] == 'bfp' and a['sparsity_mode'] == 'unstructured'
+            and a['first'] == 's' and a['rounding_mode'] == rounding_modes.DETERM and a['block_size'] > 0 and a['sparsity_frac'] > 0
+            and not sgd_update)
+
+
+def _prune_lists(tensors, a):
+    """PruneQuantizeList per (device, dtype) group of `tensors` for configuration `a`; [(indices, list)]"""
+    groups = {}
+    for i, t in enumerate(tensors):
+        native.require_device_tensor(t)
+        k = int(t.numel() * a['sparsity_frac'])
+        if k > t.numel():
+            raise RuntimeError("selected index k out of range")      # what torch.topk raises in the reference
+        groups.setdefault((t.device, t.dtype), []).append((i, k))
+    return [([i for i, _ in g], native.PruneQuantizeList([tensors[i].contiguous() for i, _ in g], [k for _, k in g],
+                                                         a['block_size'], a['mant_bits'], a['epsilon'])) for g in groups.values()]
+
+
 def float_to_bfp_blocked_many(tensors, identifier='', **bfp_args):
     """float_to_bfp_blocked (bfp_ops.py:124-149) for a LIST of tensors with one configuration -- e.g. every Linear weight of
-    a model -- in as few launches as possible (one per 64 tensors per dtype/device for the 'bfp' format with structured or no
-    pruning and round-half-even; anything else is done tensor by tensor).  Returns the list of results in order."""
+    a model -- in as few launches as possible: one per 64 tensors per dtype/device for the 'bfp' format with structured or no
+    pruning and round-half-even; for unstructured pruning before quantization, two launches per tensor pipelined over two
+    streams (native.PruneQuantizeList); anything else is done tensor by tensor.  Returns the list of results in order."""
     a = unpack_bfp_args(dict(bfp_args))
     tensors = list(tensors)
     sparsity = _select_sparsity(a['in_sparsity'], a['w_sparsity'], a['grad_sparsity'], identifier)
+    if _unstructured_lean(a, sparsity, bool(bfp_args.get('sgd_update'))):
+        out = [None] * len(tensors)
+        for idx, pl in _prune_lists(tensors, a):
+            for i, y in zip(idx, pl.run()):
+                out[i] = y.view(tensors[i].shape)
+        return out
     lean = (a['num_format'] == 'bfp' and a['sparsity_num_format'] == 'bfp' and a['rounding_mode'] == rounding_modes.DETERM
             and a['block_size'] > 0 and not bfp_args.get('sgd_update')
             and (not sparsity or (a['sparsity_mode'] == 'structured' and 0 < a['N'] <= a['M'])))
@@ -286,8 +313,8 @@ def float_to_bfp_blocked_many(tensors, identifier='', **bfp_args):
 
 class PreparedMany:
     """float_to_bfp_blocked_many with the per-call host work done once: run() re-quantizes the bound tensors (whose storage
-    must stay put, e.g. a model's weights) into the same output tensors -- one launch per 64 tensors, one ctypes call per
-    dtype/device group."""
+    must stay put, e.g. a model's weights) into the same output tensors -- one launch per 64 tensors (structured / dense), or
+    the two-stream pipeline of the unstructured path; one ctypes call per dtype/device group."""
 
     def __init__(self, tensors, identifier='', **bfp_args):
         a = unpack_bfp_args(dict(bfp_args))
@@ -297,7 +324,12 @@ class PreparedMany:
         lean = (a['num_format'] == 'bfp' and a['sparsity_num_format'] == 'bfp' and a['rounding_mode'] == rounding_modes.DETERM
                 and a['block_size'] > 0 and (not sparsity or (a['sparsity_mode'] == 'structured' and 0 < a['N'] <= a['M'])))
         self._groups = None
-        if lean:
+        if _unstructured_lean(a, sparsity):
+            for t in self.tensors:
+                if not t.is_contiguous():
+                    raise ValueError("PreparedMany needs contiguous inputs (their storage is bound)")
+            self._groups = _prune_lists(self.tensors, a)
+        elif lean:
             nm = sparsity and a['N'] < a['M']
             f = _fast_quant(a['block_size'], a['mant_bits'], a['epsilon'], a['N'] if nm else 0, a['M'] if nm else 0, a['first'] == 's')
             groups = {}

@@ -225,10 +225,11 @@ constexpr int kCutWGs = 32;                   // workgroups of the apply launch 
 struct SelWs {
     bfpq_select_state st;
     uint32_t ticket;                          // fused histogram + resolve launch: workgroups that have published their segment
-    uint32_t epoch;                           // resident kernel: bumped by the resolving workgroup once res_pub is in memory
     uint32_t error;                           // resident kernel: set when a workgroup gave up waiting for the epoch (its output is missing)
-    uint32_t pad_;
+    uint32_t pad_[2];
     uint32_t res_pub[8];                      // resident kernel: {tau, k > 0, cut_lo, cut_hi, cut_within} for the waiting workgroups
+    uint32_t epoch[32];                       // resident kernel: [0] is bumped by the resolving workgroup once res_pub is in memory; a 128-byte
+                                              // line of its own: up to 255 workgroups poll it while the late ones still draw tickets
     uint32_t coarse[BFPQ_SELECT_HIST_COPIES][kCoarseBins];   // fused launch: coarse histogram (256 bins of 128), zero between calls
     // histogram buffers of the launch-pair path (fp32; diagnostics), one per radix pass; all zero between calls: the APPLY launch
     // clears what the histogram launches of its call dirtied (see thr_setup; bfpq_select_reset after a select with no apply)

@@ -711,13 +711,14 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
         const int64_t lastv = a.n_items - 1;
         STAMP(0, 0);
         uint32_t epoch0 = 0;
-        if (t == 0) epoch0 = pub_load(&ws->epoch);
+        if (t == 0) epoch0 = pub_load(&ws->epoch[0]);
         u4v d[RES];
 #pragma unroll
         for (int j = 0; j < RES; j++) {
+            // (unconditional, index clamped: a load inside a branch would make the waits below drain the whole queue; the host
+            // picks the smallest RES that covers the segment, so few of these read past it)
             const int64_t it = i0 + t + (int64_t)j * kSelThreads;
-            if ((int64_t)j * kSelThreads < g.L) d[j] = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(src + (it < lastv ? it : lastv)));   // (block-uniform condition)
-            else d[j] = (u4v){0u, 0u, 0u, 0u};
+            d[j] = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(src + (it < lastv ? it : lastv)));
         }
         for (int i = t; i < kFineBins / 4; i += kSelThreads) reinterpret_cast<uint4*>(s_hist)[i] = make_uint4(0, 0, 0, 0);
         for (int i = t; i < 512; i += kSelThreads) s_win[i] = (a.exp_win && i < BFPQ_EXP_WIN_ENTRIES) ? a.exp_win[i] : 0;
@@ -752,10 +753,10 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_start) :: "memory");
             uint32_t ok = 0;
             for (;;) {
-                if (pub_load(&ws->epoch) != epoch0) { ok = 1; break; }
+                if (pub_load(&ws->epoch[0]) != epoch0) { ok = 1; break; }
                 asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now) :: "memory");
                 if (t_now - t_start > (unsigned long long)res_timeout) break;
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(24);                            // (~0.7 us between polls: 255 workgroups read this one line)
             }
             s_pub[7] = ok;
             if (ok) {
@@ -802,10 +803,15 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
                 body(std::true_type{}, it, u4(dj));
             }
         };
-        static_assert(RES == 13, "resident form: the item steps below are spelled out for 13 items per thread");
-        step(0, d[0]); step(1, d[1]); step(2, d[2]); step(3, d[3]); step(4, d[4]); step(5, d[5]); step(6, d[6]);
-        step(7, d[7]); step(8, d[8]); step(9, d[9]); step(10, d[10]); step(11, d[11]); step(12, d[12]);
+        static_assert(RES == 4 || RES == 8 || RES == 13, "resident form: the item steps below are spelled out for 4, 8 or 13 items per thread");
+        step(0, d[0]); step(1, d[1]); step(2, d[2]); step(3, d[3]);
+        if constexpr (RES > 4) { step(4, d[4]); step(5, d[5]); step(6, d[6]); step(7, d[7]); }
+        if constexpr (RES > 8) { step(8, d[8]); step(9, d[9]); step(10, d[10]); step(11, d[11]); step(12, d[12]); }
         STAMP(1, 1);
+#ifdef BFPQ_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(1, 2);
+#endif
         return;
     }
     // Sweep: item = sweep * stride + global thread id.  Loads run two sweeps ahead of the item being
@@ -1018,16 +1024,19 @@ int launch_resident(const FusedArgs& a, int64_t k, uint32_t timeout_ticks, hipSt
         if (g.L > (int64_t)kResItems * kSelThreads || !(a.lpb == 8 || a.lpb == 4)) return BFPQ_E_UNSUPPORTED;
         const size_t lds = sizeof(uint32_t) * kFineBins;
         const dim3 grid(g.G), block(kSelThreads);
-#define BFPQ_RES(LP) do { \
+#define BFPQ_RES(LP, R) do { \
             static bool attr_set = false; \
             if (!attr_set) { \
-                const hipError_t err = hipFuncSetAttribute((const void*)k_prune_quantize_resident<DT, LP, kResItems>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                const hipError_t err = hipFuncSetAttribute((const void*)k_prune_quantize_resident<DT, LP, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
                 if (err != hipSuccess) return (int)err; \
                 attr_set = true; \
             } \
-            hipLaunchKernelGGL((k_prune_quantize_resident<DT, LP, kResItems>), grid, block, lds, s, a, k, timeout_ticks); \
+            hipLaunchKernelGGL((k_prune_quantize_resident<DT, LP, R>), grid, block, lds, s, a, k, timeout_ticks); \
         } while (0)
-        if (a.lpb == 8) BFPQ_RES(8); else BFPQ_RES(4);
+        // items per thread: the smallest instantiation that holds the segment
+        if (g.L <= 4 * kSelThreads) { if (a.lpb == 8) BFPQ_RES(8, 4); else BFPQ_RES(4, 4); }
+        else if (g.L <= 8 * kSelThreads) { if (a.lpb == 8) BFPQ_RES(8, 8); else BFPQ_RES(4, 8); }
+        else { if (a.lpb == 8) BFPQ_RES(8, kResItems); else BFPQ_RES(4, kResItems); }
 #undef BFPQ_RES
         return (int)hipGetLastError();
     } else return BFPQ_E_UNSUPPORTED;

@@ -98,22 +98,31 @@ __device__ __forceinline__ bool seg_publish_and_ticket(const uint32_t* s_hist, u
 // A segment whose window does not cover C although it has magnitudes outside its window is counted again here (one
 // workgroup: slow, correct, and only for tensors whose segments live on wildly different scales).
 // ---------------------------------------------------------------------------------------------
+// value of `v` in the lowest lane whose `cond` holds (0 when none does), for every lane
+__device__ __forceinline__ uint32_t pick_lane(bool cond, uint32_t v)
+{
+    const unsigned long long m = __ballot(cond);
+    if (!m) return 0u;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)__ffsll((long long)m) - 1));
+}
+
 template <int DT, bool FAST>
 __device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int64_t n_items, const SegGeom g, int64_t k, SelWs* ws, uint32_t* lds, bool publish)
 {
     constexpr int VEC = Traits<DT>::VEC;
     constexpr int NC = BFPQ_SELECT_HIST_COPIES;
-    // ONE compute unit runs this while the rest of the chip idles: every instruction counts.  No branches around the loads:
-    // per segment one LDS word says where its slice for C lies (or that it has none), the 32 K slice words come as 16-byte
-    // cache-bypassing buffer loads, eight per thread, all in flight together.
+    // ONE compute unit runs this while the rest of the chip idles (or waits for it): every instruction and every barrier
+    // counts.  The scans over 256 coarse bins, 128 fine bins and 256 segments are each done by ONE wave (DPP scan, a few
+    // values per lane); the 32 K window-slice words come as 16-byte cache-bypassing buffer loads, eight per thread, all in
+    // flight together, with no branch around them (per segment one LDS word says where its slice for C lies, or that it has none).
     uint32_t* s_off = lds;               // [256] word offset of the segment's slice inside ws->windows | bit 31: no slice
     uint32_t* s_tc = lds + 256;          // [256]
     uint32_t* s_fine = lds + 512;        // [32][128]
-    uint32_t* s_part = lds + 4608;       // [16]
     uint32_t* s_r = lds + 4624;          // [16]
     uint32_t* s_h = lds + 4640;          // [128]
     uint32_t* s_segwin = lds + 4768;     // [256]
-    const int t = threadIdx.x;
+    uint32_t* s_cv = lds + 5024;         // [256]
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     STAMP(2, 0);
     uint32_t cv = 0;
     if (t < kCoarseBins) {
@@ -122,14 +131,21 @@ __device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int
     }
     const uint32_t sw = t < g.G ? pub_load(&ws->seg_win[t]) : 0u;
     __syncthreads();                                         // (the histogram's LDS is dead from here on)
-    if (t < kMaxSeg) s_segwin[t] = sw;
-    if (t < 16) s_r[t] = 0;
-    const uint32_t k_rem = (uint32_t)k;
-    uint32_t total;
-    uint32_t excl = block_excl_scan(cv, s_part, &total);     // (its barriers also order the resets above)
-    if (cv && excl < k_rem && k_rem <= excl + cv) { s_r[0] = (uint32_t)t; s_r[1] = excl; }
+    if (t < kMaxSeg) { s_segwin[t] = sw; s_cv[t] = cv; }
     __syncthreads();
-    const uint32_t C = s_r[0], before = s_r[1];              // (k == 0: bin 0, nothing in front of it)
+    const uint32_t k_rem = (uint32_t)k;
+    if (wv == 0) {                                           // coarse bins: four per lane
+        const uint4 c4 = *reinterpret_cast<const uint4*>(&s_cv[4 * lane]);
+        const uint32_t mine = c4.x + c4.y + c4.z + c4.w;
+        const uint32_t excl = wave_incl_scan(mine) - mine;
+        const bool hit = mine && excl < k_rem && k_rem <= excl + mine;
+        uint32_t bin = 4u * lane, e = excl;
+        if (k_rem > e + c4.x) { e += c4.x; bin++; if (k_rem > e + c4.y) { e += c4.y; bin++; if (k_rem > e + c4.z) { e += c4.z; bin++; } } }
+        const uint32_t C0 = pick_lane(hit, bin), b0 = pick_lane(hit, e);
+        if (lane == 0) { s_r[0] = C0; s_r[1] = b0; s_r[2] = 0; s_r[3] = 0; s_r[4] = 0; }      // (k == 0: bin 0, nothing in front of it)
+    }
+    __syncthreads();
+    const uint32_t C = s_r[0], before = s_r[1];
     STAMP(2, 1);
     for (int i = t; i < NC * kCoarseBins; i += kSelThreads) (&ws->coarse[0][0])[i] = 0u;     // zero for the next call
     // segments whose window cannot answer for C
@@ -193,13 +209,18 @@ __device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int
     *reinterpret_cast<v4u*>(&s_fine[sg * 128 + 4 * q]) = sum;
     __syncthreads();
     STAMP(2, 3);
-    uint32_t fv = 0;
-    if (t < 128) {
+    if (wv == 0) {                                           // the 128 fine bins of C: two per lane
+        uint32_t f0 = 0, f1 = 0;
 #pragma unroll
-        for (int i = 0; i < 32; i++) fv += s_fine[i * 128 + t];
+        for (int i = 0; i < 32; i++) { const uint2 p = *reinterpret_cast<const uint2*>(&s_fine[i * 128 + 2 * lane]); f0 += p.x; f1 += p.y; }
+        const uint32_t mine = f0 + f1;
+        const uint32_t excl = before + wave_incl_scan(mine) - mine;
+        const bool hit = mine && excl < k_rem && k_rem <= excl + mine;
+        const bool second = k_rem > excl + f0;
+        const uint32_t tau0 = pick_lane(hit, (C << 7) + 2u * lane + (second ? 1u : 0u));
+        const uint32_t run0 = pick_lane(hit, second ? excl + f0 : excl), ties0 = pick_lane(hit, second ? f1 : f0);
+        if (lane == 0) { s_r[2] = tau0; s_r[3] = run0; s_r[4] = ties0; }
     }
-    excl = before + block_excl_scan(fv, s_part, &total);
-    if (fv && excl < k_rem && k_rem <= excl + fv) { s_r[2] = (C << 7) + (uint32_t)t; s_r[3] = excl; s_r[4] = fv; }
     __syncthreads();
     const uint32_t tau = s_r[2], run = s_r[3], ties = s_r[4];
     const uint32_t need = k_rem - run;
@@ -211,26 +232,41 @@ __device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int
         for (int j = 0; j < kMaxSeg / 32; j++) s_tc[sg + 32 * j] = comp == 0 ? cnt[j][0] : (comp == 1 ? cnt[j][1] : (comp == 2 ? cnt[j][2] : cnt[j][3]));
     }
     __syncthreads();
-    const uint32_t tc = t < g.G ? s_tc[t] : 0u;
-    cut_from_seg_ties(tc, (int64_t)need, g, n_items, s_part, s_r + 8);
-    STAMP(2, 5);
-    if (t == 0) {
-        bfpq_select_state* st = &ws->st;
-        st->prefix = tau; st->prefix_mask = 0x7fffu; st->k_rem = (int64_t)need; st->tau = tau; st->done = 1;
-        st->need = (int64_t)need; st->ties = (int64_t)ties; st->k = k; st->tie_base = 0;
-        st->flags = 1u; st->cut_lo = s_r[8]; st->cut_hi = s_r[9]; st->cut_within = s_r[10];
-        st->reserved[0] = st->reserved[1] = 0;
-        ws->ticket = 0u;                                     // ready for the next call
-        if (publish) {
-            // the resident kernel's other workgroups are waiting for exactly these words: write-through stores, drained, then
-            // the epoch they poll
-            pub_store(&ws->res_pub[0], tau); pub_store(&ws->res_pub[1], k > 0 ? 1u : 0u);
-            pub_store(&ws->res_pub[2], s_r[8]); pub_store(&ws->res_pub[3], s_r[9]); pub_store(&ws->res_pub[4], s_r[10]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add(&ws->epoch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wv == 0) {                                           // the cut: 256 segments, four per lane
+        const uint4 c4 = *reinterpret_cast<const uint4*>(&s_tc[4 * lane]);
+        const uint32_t v[4] = {4 * lane < g.G ? c4.x : 0u, 4 * lane + 1 < g.G ? c4.y : 0u, 4 * lane + 2 < g.G ? c4.z : 0u, 4 * lane + 3 < g.G ? c4.w : 0u};
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        const uint32_t incl = wave_incl_scan(mine), excl = incl - mine;
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t n_round = (uint32_t)((n_items + 63) / 64 * 64);
+        uint32_t lo = 0, hi = 0, within = 0;
+        if (need >= total && need > 0) { lo = hi = n_round; }            // every tie goes ((need == 0: none does)
+        else if (need > 0) {
+            const bool hit = mine && excl <= need && need < excl + mine;
+            uint32_t seg = 4u * lane, e = excl;
+            if (need >= e + v[0]) { e += v[0]; seg++; if (need >= e + v[1]) { e += v[1]; seg++; if (need >= e + v[2]) { e += v[2]; seg++; } } }
+            const uint32_t B = pick_lane(hit, seg), w0 = pick_lane(hit, need - e);
+            const int64_t b0 = (int64_t)B * g.L, b1 = b0 + g.L < n_items ? b0 + g.L : n_items;
+            lo = (uint32_t)b0; hi = w0 ? (uint32_t)b1 : (uint32_t)b0; within = w0;
+        }
+        STAMP(2, 5);
+        if (lane == 0) {
+            bfpq_select_state* st = &ws->st;
+            st->prefix = tau; st->prefix_mask = 0x7fffu; st->k_rem = (int64_t)need; st->tau = tau; st->done = 1;
+            st->need = (int64_t)need; st->ties = (int64_t)ties; st->k = k; st->tie_base = 0;
+            st->flags = 1u; st->cut_lo = lo; st->cut_hi = hi; st->cut_within = within;
+            st->reserved[0] = st->reserved[1] = 0;
+            ws->ticket = 0u;                                     // ready for the next call
+            if (publish) {
+                // the resident kernel's other workgroups are waiting for exactly these words: write-through stores, drained, then
+                // the epoch they poll
+                pub_store(&ws->res_pub[0], tau); pub_store(&ws->res_pub[1], k > 0 ? 1u : 0u);
+                pub_store(&ws->res_pub[2], lo); pub_store(&ws->res_pub[3], hi); pub_store(&ws->res_pub[4], within);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(&ws->epoch[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
-
 
 }  // namespace bfpq_dev

@@ -84,6 +84,7 @@ def load_library():
         L.bfpq_select.argtypes = [vp, i64, i32, i64, vp, vp]
         L.bfpq_prune_quantize.argtypes = [vp, vp, i64, i64, i32, i32, i32, dbl, i64, vp, vp, vp]
         L.bfpq_prune_quantize_is_resident.argtypes = [vp, vp, i64, i64, i32, i32]
+        L.bfpq_prune_quantize_batched.argtypes = [vp, i32, i32, i32, i32, dbl, vp, vp, i32, vp, vp]
         L.bfpq_select_error.argtypes = [vp, vp]
         L.bfpq_select_hist.argtypes = [vp, i64, i32, i32, i64, i64, vp, vp, vp]
         L.bfpq_select_resolve.argtypes = [vp, i64, i32, i32, i64, vp, i32, i32, vp, vp, vp]
@@ -106,7 +107,7 @@ def load_library():
         L.bfpq_hbfp_linear_mx8_splitk.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, i64, i32, vp]
         for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_is_fused", "bfpq_nm_sparsify",
                      "bfpq_select_passes", "bfpq_select", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
-                     "bfpq_prune_quantize", "bfpq_prune_quantize_is_resident", "bfpq_select_error",
+                     "bfpq_prune_quantize", "bfpq_prune_quantize_is_resident", "bfpq_prune_quantize_batched", "bfpq_select_error",
                      "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize", "bfpq_hbfp_linear_slices",
                      "bfpq_hbfp_linear_decode", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled",
                      "bfpq_mx8_from_hbfp", "bfpq_quantize_mx8", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8",
@@ -119,7 +120,7 @@ def load_library():
 EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_mx8_parts", "bfpq_hbfp_linear_mx8_splitk", "bfpq_quantize_mx8", "bfpq_mx8_from_hbfp", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_select_ws_bytes", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_is_fused", "bfpq_nm_sparsify",
                     "bfpq_select_passes", "bfpq_select", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
-                    "bfpq_prune_quantize", "bfpq_prune_quantize_is_resident", "bfpq_select_error",
+                    "bfpq_prune_quantize", "bfpq_prune_quantize_is_resident", "bfpq_prune_quantize_batched", "bfpq_select_error",
                     "bfpq_threshold_apply", "bfpq_quantize_threshold")
 
 
@@ -535,6 +536,83 @@ def prune_quantize(t, k, ws, block_size, mant_bits, epsilon, out=None):
                                     int(k), _ptr(exp_window_dev(src.dtype, dev)), _ptr(ws.ws), _stream(src)), "bfpq_prune_quantize")
         ws.dirty = False
     return dst
+
+
+class _PruneDesc(ctypes.Structure):
+    """include/bfpq.h: bfpq_prune_desc"""
+    _fields_ = [("in_dev", ctypes.c_void_p), ("out_dev", ctypes.c_void_p), ("rows", ctypes.c_int64), ("cols", ctypes.c_int64), ("k", ctypes.c_int64)]
+
+
+_aux_streams = {}
+
+
+def aux_stream(device):
+    """the side stream (one per device) on which bfpq_prune_quantize_batched runs the apply launches"""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    s = _aux_streams.get(idx)
+    if s is None:
+        s = _aux_streams[idx] = torch.cuda.Stream(torch.device("cuda", idx))
+    return s
+
+
+class PruneQuantizeList:
+    """A list of tensors of one dtype on one device bound to the s-first unstructured drop-in op (bfpq_prune_quantize_batched):
+    outputs, descriptors and the workspaces are set up once; run() is ONE ctypes call that pipelines the tensors over the
+    current stream and a side stream (selection of tensor i + 1 beside the prune + quantize pass of tensor i).
+    ks: elements to prune per tensor, int(numel * frac) as the reference computes it (bfp_ops.py:66)."""
+
+    N_WS = 4
+
+    def __init__(self, tensors, ks, block_size, mant_bits, epsilon, outs=None):
+        tensors = list(tensors)
+        self.block_size, self.mant_bits, self.epsilon = int(block_size), int(mant_bits), float(epsilon)
+        self.outputs = [None] * len(tensors)
+        self._bound = []
+        self._descs = (_PruneDesc * max(len(tensors), 1))()
+        self._n = 0
+        self.device = self.dtype = None
+        for i, (t, k) in enumerate(zip(tensors, ks)):
+            require_device_tensor(t)
+            if self.device is None:
+                self.device, self.dtype = t.device, t.dtype
+            if t.device != self.device or t.dtype != self.dtype:
+                raise ValueError("PruneQuantizeList: the tensors of one list share device and dtype")
+            if not t.is_contiguous():
+                raise ValueError("PruneQuantizeList needs contiguous inputs (their storage is bound)")
+            dst = torch.empty_like(t) if outs is None or outs[i] is None else outs[i]
+            self.outputs[i] = dst
+            if t.numel() == 0:
+                continue
+            rows, cols = rows_cols(t)
+            d = self._descs[self._n]
+            d.in_dev, d.out_dev, d.rows, d.cols, d.k = t.data_ptr(), dst.data_ptr(), rows, cols, int(k)
+            self._bound.append((t, t.data_ptr(), t.numel()))
+            self._n += 1
+        if self._n:
+            with torch.cuda.device(self.device):
+                self._ws = [SelectWorkspace(self.device) for _ in range(self.N_WS)]
+                self._ws_ptrs = (ctypes.c_void_p * self.N_WS)(*[w.ws.data_ptr() for w in self._ws])
+                self._win = exp_window_dev(self.dtype, self.device)
+                self._aux = aux_stream(self.device)
+        self._fn = load_library().bfpq_prune_quantize_batched
+
+    def run(self, pipelined=True):
+        if self._n:
+            for j, (t, ptr, n) in enumerate(self._bound):                 # follow tensors whose storage moved (see PreparedList)
+                cur = t.data_ptr()
+                if cur != ptr:
+                    if t.dtype != self.dtype or t.device != self.device or t.numel() != n or not t.is_contiguous():
+                        raise RuntimeError("PruneQuantizeList: a bound tensor changed dtype / device / size / layout since it was bound; build a new list")
+                    self._descs[j].in_dev = cur
+                    self._bound[j] = (t, cur, n)
+            dev = self.device
+            with torch.cuda.device(dev):
+                rc = self._fn(ctypes.addressof(self._descs), self._n, DTYPE_CODE[self.dtype], self.block_size, self.mant_bits, self.epsilon,
+                              self._win.data_ptr(), ctypes.addressof(self._ws_ptrs), self.N_WS, torch.cuda.current_stream(dev).cuda_stream,
+                              self._aux.cuda_stream if pipelined else None)
+            if rc:
+                check(rc, "bfpq_prune_quantize_batched")
+        return self.outputs
 
 
 def select_error(ws):
