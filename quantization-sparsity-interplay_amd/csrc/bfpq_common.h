@@ -123,6 +123,9 @@ __device__ __forceinline__ BlockScale block_scale(uint32_t max_key, int mant_bit
     const float p2em = ldexpf(1.0f, em);
     b.e = e;
     b.interval = rnd<DT>(p2em);
+    // interval underflows to 0 in dtype (fp16: block max below 2^(m - 24)): the reference divides by it -- 0 / 0 and
+    // (x / 0) * 0 are NaN for every element -- so this is a NaN block as well, and the packed exponent must say so
+    if (b.interval == 0.f) { b.e = -128; return b; }
     const float p2e = rnd<DT>(ldexpf(1.0f, e));
     b.max_v = rnd<DT>(p2e - b.interval);
     const bool fast = (mant_bits <= T::SIG) && (b.interval == p2em) && (em >= -126) && (em <= 126) &&

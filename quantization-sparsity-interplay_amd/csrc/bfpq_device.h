@@ -516,10 +516,10 @@ inline int grid_for_cap(int64_t work_threads, int64_t cap)
     return (int)((g + sweeps - 1) / sweeps);
 }
 inline int grid_for(int64_t work_threads) { return grid_for_cap(work_threads, kMaxGrid); }
-// The packed-output instantiations write a quarter (4-bit codes) or half (e4m3 image) of the bytes they read: HBM is not the
-// limit (3.9 TB/s of traffic at the drop-in grid), the number of loads in flight is.  They fit 64 VGPRs, so the cap is raised to
-// fill all 8 wave slots per SIMD (interleaved sweep on [4096,11008] bf16 2:4 packed, tools_dev/ab_grid.py with PACKED=1:
-// 1024 workgroups 29.0 us, 1536 27.8, 2048 26.6, 2752 26.2, 4096 26.6).
-inline int grid_for_packed(int64_t work_threads) { return grid_for_cap(work_threads, (int64_t)kMaxGrid * 43 / 16); }
+// The packed-output instantiations write a quarter (4-bit codes) or half (e4m3 image) of the bytes they read.  After the r03 diet
+// (83 vector instructions per item instead of 148) and with two sweeps of loads in flight they are bound by bytes in flight, and fit
+// 64 VGPRs: the cap is two workgroups per SIMD slot pair = 2048, one full round of the chip at 8 waves per SIMD (interleaved sweep on
+// [4096,11008] bf16 2:4 packed, tools_dev/ab_packed.py: 1024 workgroups 24.1 us, 1536 24.1, 2048 23.1, 2752 23.4).
+inline int grid_for_packed(int64_t work_threads) { return grid_for_cap(work_threads, (int64_t)kMaxGrid * 2); }
 
 }  // namespace bfpq_dev

@@ -254,6 +254,26 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
         [[maybe_unused]] uint32_t pack_w = 0, pack_w2 = 0;        // PACK4: the item's eight 4-bit codes (MX8: eight e4m3 bytes), the block's exponent byte
         [[maybe_unused]] int pack_e = 0;
         [[maybe_unused]] bool pack_hot = false;
+        // packed item of the general tiers, from code[] / e_blk / nan_blk.  Called INSIDE their branch where nothing comes between
+        // (dense or sparsify-first): with the packing behind the merge, the eight codes were live across it and the hot path paid
+        // eight register moves per item for values it never uses.
+        [[maybe_unused]] auto pack_cold = [&]() __attribute__((always_inline)) {
+            if constexpr (MX8) {
+                auto b8 = [](float cf) { const int c = (int)cf; const uint32_t m = (uint32_t)(c < 0 ? -c : c);
+                                         const uint32_t v = m >= 8 ? 0x48u + m : (m >= 4 ? 0x40u + 2u * m : (m >= 2 ? 0x38u + 4u * m : 0x38u));
+                                         return (m ? v : 0u) | (c < 0 ? 0x80u : 0u); };
+                pack_w = pack_w2 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { pack_w |= b8(code[j]) << (8 * j); pack_w2 |= b8(code[(4 + j) % VEC]) << (8 * j); }
+                pack_e = nan_blk ? 0x7fffffff : e_blk;                       // (the E8M0 conversion below maps the marker to 0xff)
+            } else if constexpr (PACK4) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int j = 0; j < VEC; j++) w |= ((uint32_t)(int)code[j] & 0xfu) << (4 * j);
+                pack_w = w;
+                pack_e = nan_blk ? -128 : (e_blk < -127 ? -127 : (e_blk > 127 ? 127 : e_blk));
+            }
+        };
         if (do_quant) {
             // block max of |v| as integer max of magnitude bits
             uint32_t mx;
@@ -282,7 +302,36 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
                     // -> one dword.  The eight block exponents of the wave leave as ONE 8-byte store.
                     static_assert(LPBT == 8, "packed 4-bit instantiation: block = 8 lane items");
                     const uint32_t absm = T::ABS | (T::ABS << 16);
-                    uint32_t dd[4] = {d0, d1, d2, d3}, q[4];
+                    uint32_t dd[4] = {d0, d1, d2, d3};
+                    if constexpr (!MX8 && (NM == 0 || SFIRST)) {
+                        // 4-bit codes straight from the SIGNED values: clamp(x, +-max_v) + C with C = 1.5 * 2^23 * interval leaves
+                        // round(x / interval) as a two's-complement integer in the low bits of the float image (the classic
+                        // float -> int constant), so the low nibble of each sum IS the code: no sign fix-up afterwards.  The
+                        // clamp: two v_med3_f32 per dword (bf16, after the unpack) or v_pk_max/min_f16 on the packed halves (fp16).
+                        typedef float float2v __attribute__((ext_vector_type(2)));
+                        const float2v C2 = {h16.C, h16.C};
+                        uint32_t g[4];
+#pragma unroll
+                        for (int x = 0; x < 4; x++) {
+                            float2v v;
+                            if constexpr (DT == BFPQ_BF16) {
+                                const float mv = u2f(h16.maxv2 << 16);
+                                v = (float2v){__builtin_amdgcn_fmed3f(u2f(dd[x] << 16), -mv, mv), __builtin_amdgcn_fmed3f(u2f(dd[x] & 0xffff0000u), -mv, mv)} + C2;
+                            } else {
+                                uint32_t cl;
+                                asm("v_pk_min_f16 %0, %1, %2" : "=v"(cl) : "v"(dd[x]), "v"(h16.maxv2));
+                                asm("v_pk_max_f16 %0, %1, %2" : "=v"(cl) : "v"(cl), "v"(h16.maxv2 | 0x80008000u));
+                                v = (float2v){fma_mix_f16<false>(cl, h16.C), fma_mix_f16<true>(cl, h16.C)};
+                            }
+                            g[x] = __builtin_amdgcn_perm(f2u(v.y), f2u(v.x), 0x0c0c0400u);        // [lo.byte0, hi.byte0, 0, 0]
+                        }
+                        uint32_t p0 = __builtin_amdgcn_perm(g[1], g[0], 0x05040100u) & 0x0f0f0f0fu;    // the low nibbles of elements 0..3 / 4..7, one per byte
+                        uint32_t p1 = __builtin_amdgcn_perm(g[3], g[2], 0x05040100u) & 0x0f0f0f0fu;
+                        p0 |= p0 >> 4; p1 |= p1 >> 4;                                                  // bytes 0 and 2 now hold two nibbles each
+                        pack_w = __builtin_amdgcn_perm(p1, p0, 0x06040200u);
+                        pack_e = h16.e;
+                    } else {
+                    uint32_t q[4];
 #pragma unroll
                     for (int x = 0; x < 4; x++) {
                         const uint32_t am = pk_min_u16(dd[x] & absm, h16.maxv2);
@@ -319,6 +368,7 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
                     p0 |= p0 >> 4; p1 |= p1 >> 4;                                                  // bytes 0 and 2 now hold two nibbles each
                     pack_w = __builtin_amdgcn_perm(p1, p0, 0x06040200u);
                     pack_e = h16.e;
+                    }
                     }
                 } else if constexpr (VEC == 8 && !STOCH && DEQ_ONLY) {
                     const uint32_t absm = T::ABS | (T::ABS << 16);
@@ -411,6 +461,7 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
                         o3 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(y[6], y[7]));
                     }
                 }
+                if constexpr (PACK4 && (NM == 0 || SFIRST)) pack_cold();
             }
         }
         if constexpr (NM != 0 && !SFIRST) if (!(PACK4 && pack_hot)) {                // Q before S (bfp_ops.py:146-149)
@@ -429,39 +480,35 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
         }
         if constexpr (PACK4) {
             // the packed item from whichever tier ran; then stores that are unconditional in form (a store inside a branch makes
-            // hipcc drain the memory queue at the loop top): every lane its code dword, and the wave's eight exponent bytes as
-            // ONE 8-byte value that all lanes write to the same address
-            if (!pack_hot) {
-                if constexpr (MX8) {
-                    auto b8 = [](float cf) { const int c = (int)cf; const uint32_t m = (uint32_t)(c < 0 ? -c : c);
-                                             const uint32_t v = m >= 8 ? 0x48u + m : (m >= 4 ? 0x40u + 2u * m : (m >= 2 ? 0x38u + 4u * m : 0x38u));
-                                             return (m ? v : 0u) | (c < 0 ? 0x80u : 0u); };
-                    pack_w = pack_w2 = 0;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { pack_w |= b8(code[j]) << (8 * j); pack_w2 |= b8(code[(4 + j) % VEC]) << (8 * j); }
-                    pack_e = e_blk;
-                } else {
-                    uint32_t w = 0;
-#pragma unroll
-                    for (int j = 0; j < VEC; j++) w |= ((uint32_t)(int)code[j] & 0xfu) << (4 * j);
-                    pack_w = w;
-                    pack_e = nan_blk ? -128 : (e_blk < -127 ? -127 : (e_blk > 127 ? 127 : e_blk));
-                }
-            }
+            // hipcc drain the memory queue at the loop top): every lane its code dword; the block's exponent byte from the first
+            // lane of each block
+            if constexpr (NM != 0 && !SFIRST) { if (!pack_hot) pack_cold(); }       // (else: done inside the general tier's branch)
             if constexpr (MX8) {                                  // E8M0 scale of the block: 2^(e - mant_bits), NaN block -> 0xff
-                const int sc = pack_e - a.mant_bits + 127;
-                pack_e = (!pack_hot && nan_blk) ? 0xff : (sc < 0 ? 0 : (sc > 254 ? 254 : sc));
+                if (pack_e == 0x7fffffff) pack_e = 0xff;
+                else { const int sc = pack_e - a.mant_bits + 127; pack_e = sc < 0 ? 0 : (sc > 254 ? 254 : sc); }
             }
             if constexpr (!GUARD) {
-                if constexpr (MX8) reinterpret_cast<uint2*>(a.out_codes)[item] = make_uint2(pack_w, pack_w2);
-                else reinterpret_cast<uint32_t*>(a.out_codes)[item] = pack_w;
-                const int e8 = pack_e & 0xff;
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(e8, 0) | ((uint32_t)__builtin_amdgcn_readlane(e8, 8) << 8) |
-                                    ((uint32_t)__builtin_amdgcn_readlane(e8, 16) << 16) | ((uint32_t)__builtin_amdgcn_readlane(e8, 24) << 24);
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane(e8, 32) | ((uint32_t)__builtin_amdgcn_readlane(e8, 40) << 8) |
-                                    ((uint32_t)__builtin_amdgcn_readlane(e8, 48) << 16) | ((uint32_t)__builtin_amdgcn_readlane(e8, 56) << 24);
-                const int64_t tile0 = uniform64(item - (threadIdx.x & 63));
-                *reinterpret_cast<uint2*>(a.out_exp + (tile0 >> 3)) = make_uint2(lo, hi);
+                // (32-bit byte offsets from a uniform base: one shift per address; the launcher cuts tensors beyond 2^28 items)
+#if !defined(BFPQ_AB) || BFPQ_AB != 2
+                if constexpr (MX8) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out_codes) + (uint32_t)item * 8u) = make_uint2(pack_w, pack_w2);
+                else *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.out_codes) + (uint32_t)item * 4u) = pack_w;
+#else
+                if (pack_w == 0x12345u && pack_e == 77) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.out_codes) + (uint32_t)item * 4u) = pack_w;   // (A/B: no code stores)
+#endif
+                // the block's exponent byte: ONE byte store per wave-instruction with only the first lane of each block enabled
+                // (exec narrowed around it by hand -- a branch would make hipcc drain the memory queue at the loop top; the eight
+                // v_readlane + scalar packing this replaces cost 9 vector instructions per item)
+#if !defined(BFPQ_AB) || BFPQ_AB != 1
+                {
+                    unsigned long long saved;
+                    const unsigned long long lead = 0x0101010101010101ull;
+                    const uint32_t eoff = (uint32_t)item >> 3;
+                    asm volatile("s_and_saveexec_b64 %0, %4\n\tglobal_store_byte %1, %2, %3\n\ts_mov_b64 exec, %0"
+                                 : "=&s"(saved) : "v"(eoff), "v"(pack_e), "s"(a.out_exp), "s"(lead) : "memory");                 // (exec is restored inside)
+                }
+#else
+                if (pack_e == 12345) a.out_exp[item >> 3] = (int8_t)pack_e;        // (A/B: no exponent stores)
+#endif
             } else if (valid) {
                 if constexpr (MX8) reinterpret_cast<uint2*>(a.out_codes)[item] = make_uint2(pack_w, pack_w2);
                 else reinterpret_cast<uint32_t*>(a.out_codes)[item] = pack_w;
@@ -816,13 +863,21 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
     }
     // Sweep: item = sweep * stride + global thread id.  Loads run two sweeps ahead of the item being
     // processed (index clamped to the last item, never conditional).
-    const int64_t last = a.n_items - 1;
-    auto fetch = [&](int64_t i) __attribute__((always_inline)) {
-        return __builtin_nontemporal_load(reinterpret_cast<const u4v*>(src + (i < last ? i : last)));
+    // (the packed-output instantiations are bound by vector-instruction issue, not by memory: they index with 32 bits -- byte
+    // offsets from a uniform base, one shift per address instead of 64-bit compare / select / shift-add chains; the launcher
+    // cuts a tensor beyond 2^28 lane items into pieces)
+    constexpr bool IDX32 = PACK4 && !BATCHED;
+    using idx_t = std::conditional_t<IDX32, uint32_t, int64_t>;
+    const idx_t last = (idx_t)(a.n_items - 1);
+    auto fetch = [&](idx_t i) __attribute__((always_inline)) {
+        const idx_t ic = i < last ? i : last;
+        if constexpr (IDX32) return __builtin_nontemporal_load(reinterpret_cast<const u4v*>(reinterpret_cast<const char*>(src) + (uint32_t)(ic * 16u)));
+        else return __builtin_nontemporal_load(reinterpret_cast<const u4v*>(src + ic));
     };
-    const int64_t full = a.n_items / stride;                               // sweeps in which every thread has an item
+    const idx_t strd = (idx_t)stride, n_rnd = (idx_t)n_round;
+    const idx_t full = (idx_t)a.n_items / strd;                            // sweeps in which every thread has an item
     const bool cut_wg = NM == -1 && (int)blockIdx.x < kLead;
-    int64_t item = cut_wg ? (int64_t)threadIdx.x : (int64_t)((int)blockIdx.x - kLead) * kThreads + threadIdx.x;
+    idx_t item = cut_wg ? (idx_t)threadIdx.x : (idx_t)((int)blockIdx.x - kLead) * kThreads + threadIdx.x;
     u4v c0 = fetch(item);
     // Tables -> LDS, issued BEHIND the first tile's load and as one dword per thread.  The byte-per-thread loops this
     // replaces were 5 dependent global round trips (3 for the 729-byte N:M table, 2 for the window table) in front of the
@@ -883,20 +938,41 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
     asm volatile("" ::: "memory");                                         // (pins the dummy between the first load and the loop)
     const uint32_t dummy = *reinterpret_cast<const uint32_t*>(src);
     asm volatile("" ::: "memory");
-    int64_t sweep = 0;
+    idx_t sweep = 0;
+    if constexpr (IDX32) {
+        // The packed-output instantiations are not at the memory pipe's limit (a quarter / half of the bytes written) but at
+        // what ONE 1-KB load in flight per wave sustains against ~2 us of latency (8 waves x 4 SIMDs x 256 CUs x 1 KB = 8.4 MB in
+        // flight ~ 4 TB/s, which is what they measured).  So: TWO sweeps ahead, three register sets alternating by name.
+        u4v c1 = fetch(item + strd);
+        for (; sweep + 3 <= full; sweep += 3, item += 3 * strd) {
+            const u4v c2 = fetch(item + 2 * strd);
+            body(std::false_type{}, (int64_t)item, u4(c0));
+            c0 = fetch(item + 3 * strd);
+            body(std::false_type{}, (int64_t)(item + strd), u4(c1));
+            c1 = fetch(item + 4 * strd);
+            body(std::false_type{}, (int64_t)(item + 2 * strd), u4(c2));
+        }
+        for (; item < n_rnd; item += strd) {
+            const u4v c2 = fetch(item + 2 * strd);
+            body(std::true_type{}, (int64_t)item, u4(c0));
+            c0 = c1; c1 = c2;
+        }
+        asm volatile("" : : "v"(dummy));
+        return;
+    }
     // main loop: load one sweep ahead; unrolled by two so that the two register sets alternate by NAME
     // (copying a register that a load in flight will write forces vmcnt(0)); with nothing conditional in
     // the body the waits are counted and the previous store stays in flight across the loop top
-    for (; sweep + 2 <= full; sweep += 2, item += 2 * stride) {
-        const u4v c1 = fetch(item + stride);
-        body(std::false_type{}, item, u4(c0));
-        c0 = fetch(item + 2 * stride);
-        body(std::false_type{}, item + stride, u4(c1));
+    for (; sweep + 2 <= full; sweep += 2, item += 2 * strd) {
+        const u4v c1 = fetch(item + strd);
+        body(std::false_type{}, (int64_t)item, u4(c0));
+        c0 = fetch(item + 2 * strd);
+        body(std::false_type{}, (int64_t)(item + strd), u4(c1));
     }
     // remaining full sweep (0..1) and the ragged last one: guarded, rolled (block-uniform trip count)
-    for (; item < n_round; item += stride) {
-        const u4v c1 = fetch(item + stride);
-        body(std::true_type{}, item, u4(c0));
+    for (; item < n_rnd; item += strd) {
+        const u4v c1 = fetch(item + strd);
+        body(std::true_type{}, (int64_t)item, u4(c0));
         c0 = c1;
     }
     asm volatile("" : : "v"(dummy));                                       // the dummy's only "use": after all the work
@@ -974,9 +1050,18 @@ int launch_fused_l(const FusedArgs& a, hipStream_t s)
     if (deq_only) return launch_fused_o<DT, NM, SFIRST, STOCH, true>(a, s);
     if constexpr (!STOCH && Traits<DT>::VEC == 8 && NM != 2 && NM != 8) {
         // packed 4-bit codes + exponents only, block = 8 lane items: the lean packed instantiation
-        if (!a.out_deq && a.out_codes && a.code_bits == 4 && a.out_exp && a.lpb == 8 && (reinterpret_cast<uintptr_t>(a.out_exp) & 7u) == 0) {
-            const dim3 grid(grid_for_packed(a.n_items)), block(kThreads);
-            hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, false, 8, false, false, 4>), grid, block, 0, s, a);
+        if (!a.out_deq && a.out_codes && a.code_bits == 4 && a.out_exp && a.lpb == 8) {
+            // (32-bit indexing inside: pieces of 2^27 lane items -- whole blocks, whole exponent bytes)
+            const int64_t piece = (int64_t)1 << 27;
+            for (int64_t i0 = 0; i0 < a.n_items; i0 += piece) {
+                FusedArgs b = a;
+                b.in = reinterpret_cast<const char*>(a.in) + i0 * 16;
+                b.out_codes = reinterpret_cast<char*>(a.out_codes) + i0 * 4;
+                b.out_exp = a.out_exp + i0 / 8;
+                b.n_items = a.n_items - i0 < piece ? a.n_items - i0 : piece;
+                const dim3 grid(grid_for_packed(b.n_items)), block(kThreads);
+                hipLaunchKernelGGL((k_fused_flat<DT, NM, SFIRST, false, 8, false, false, 4>), grid, block, 0, s, b);
+            }
             return (int)hipGetLastError();
         }
     }
@@ -995,8 +1080,16 @@ template <int DT>
 int launch_fused_mx8(const FusedArgs& a, hipStream_t s)
 {
     if constexpr (Traits<DT>::VEC == 8) {
-        const dim3 grid(grid_for_packed(a.n_items)), block(kThreads);
-        hipLaunchKernelGGL((k_fused_flat<DT, 0, true, false, 8, false, false, 8>), grid, block, 0, s, a);
+        const int64_t piece = (int64_t)1 << 27;               // (32-bit indexing inside: see launch_fused_l)
+        for (int64_t i0 = 0; i0 < a.n_items; i0 += piece) {
+            FusedArgs b = a;
+            b.in = reinterpret_cast<const char*>(a.in) + i0 * 16;
+            b.out_codes = reinterpret_cast<char*>(a.out_codes) + i0 * 8;
+            b.out_exp = a.out_exp + i0 / 8;
+            b.n_items = a.n_items - i0 < piece ? a.n_items - i0 : piece;
+            const dim3 grid(grid_for_packed(b.n_items)), block(kThreads);
+            hipLaunchKernelGGL((k_fused_flat<DT, 0, true, false, 8, false, false, 8>), grid, block, 0, s, b);
+        }
         return (int)hipGetLastError();
     } else return BFPQ_E_UNSUPPORTED;
 }

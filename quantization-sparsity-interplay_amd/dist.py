@@ -40,7 +40,7 @@ def all_gather_into(out, inp, group=None):
         dist.all_gather_into_tensor(host.view(-1), inp.contiguous().view(-1).cpu(), group=group)
         out.copy_(host)
         return
-    dist.all_gather_into_tensor(out, inp, group=group)
+    dist.all_gather_into_tensor(out.view(-1), inp.contiguous().view(-1), group=group)
 
 
 def all_gather_rows(local, rows_total, group=None):
@@ -153,19 +153,34 @@ def float_to_bfp_packed_sharded(local, rows_total, mant_bits, block_size, group=
     return codes, exps
 
 
-def gather_overlapped(local, rows_total, compute, chunks=4, group=None):
+_side_streams = {}
+
+
+def _side_stream(device):
+    """the persistent side stream (one per device) that carries the overlapped gathers"""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    s = _side_streams.get(idx)
+    if s is None:
+        s = _side_streams[idx] = torch.cuda.Stream(torch.device("cuda", idx))
+    return s
+
+
+def gather_overlapped(local, rows_total, compute, chunks=4, group=None, out=None):
     """out = all-gather over ranks of compute(local), with the gather of row-chunk i overlapped with the
     compute of chunk i+1: the slab is cut into `chunks` row pieces; each piece is computed on the current
-    stream and all-gathered on a side stream as soon as it is done (an event orders the two), straight into
-    its rows of the full result.  Needs an even row split (rows_total % world == 0).
+    stream and, as soon as it is done (an event orders the two), all-gathered on a persistent side stream with
+    ONE all_gather_into_tensor into a contiguous [world, piece rows, ...] staging buffer, from where one strided
+    copy (also on the side stream) puts every rank's piece into its rows of the full result.  Needs an even row
+    split (rows_total % world == 0).
     compute(piece) -> tensor with the same number of rows (quantize / N:M: rows are independent)."""
     world = dist.get_world_size(group)
     per = rows_total // world
     assert per * world == rows_total and local.shape[0] == per, "gather_overlapped needs an even row split"
     bounds = [per * i // chunks for i in range(chunks + 1)]
     on_gpu = local.device.type == "cuda"
-    out = None
-    side = torch.cuda.Stream(local.device) if on_gpu else None
+    side = _side_stream(local.device) if on_gpu else None
+    if on_gpu:
+        side.wait_stream(torch.cuda.current_stream(local.device))          # (the previous call's readers of `out` / the stage are done)
     for i in range(chunks):
         lo, hi = bounds[i], bounds[i + 1]
         if hi == lo:
@@ -173,16 +188,20 @@ def gather_overlapped(local, rows_total, compute, chunks=4, group=None):
         piece = compute(local[lo:hi]).contiguous()
         if out is None:
             out = torch.empty((rows_total,) + tuple(piece.shape[1:]), dtype=piece.dtype, device=piece.device)
-        views = [out[r * per + lo: r * per + hi] for r in range(world)]       # contiguous row slices of the result
+        dst = out.view((world, per) + tuple(piece.shape[1:]))[:, lo:hi]       # every rank's rows [lo, hi) of its slab
         if on_gpu:
             done = torch.cuda.Event()
             done.record()
             with torch.cuda.stream(side):
                 side.wait_event(done)
-                dist.all_gather(views, piece, group=group)
+                stage = torch.empty((world,) + tuple(piece.shape), dtype=piece.dtype, device=piece.device)
+                all_gather_into(stage, piece, group)
+                dst.copy_(stage)
                 piece.record_stream(side)
         else:
-            dist.all_gather(views, piece, group=group)
+            stage = torch.empty((world,) + tuple(piece.shape), dtype=piece.dtype)
+            dist.all_gather_into_tensor(stage.view(-1), piece.view(-1), group=group)
+            dst.copy_(stage)
     if on_gpu:
         torch.cuda.current_stream(local.device).wait_stream(side)
     return out

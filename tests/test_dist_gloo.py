@@ -26,7 +26,9 @@ def _free_port():
 
 class NumpyEngine:
     """stand-in for native.select_threshold / threshold_apply on CPU bf16/fp16 tensors (one 15-bit radix pass; same
-    histogram layout and the same all-gather callback as the HIP engine)"""
+    histogram layout and the same all-gather callback as the HIP engine).  It does NOT model fp32's three radix passes
+    (11 + 11 + 9 bits, a histogram all-gather per pass, the prefix carried between them): those run with the real kernels
+    and 2 / 3 ranks in tests/test_dist_gpu.py (fp32 tensors, real-valued and tie-heavy)."""
 
     class WS:
         pass

@@ -48,34 +48,53 @@ def _worker(rank, world, port, backend, one_device, tmpdir):
         from quantization_sparsity_interplay_amd import dist as qd
         from quantization_sparsity_interplay_amd.bfp import bfp_ops
         g = torch.Generator().manual_seed(99)
-        bits = lambda t: t.contiguous().view(torch.int16)                               # noqa: E731
-        # rows: even split, ragged split, fewer rows than ranks (empty slabs), the LLaMA-7B q_proj shape
-        for rows, cols in ((64, 256), (37, 512), (1, 128), (4096, 4096)):
-            for tag in ("real", "coarse"):
-                full_c = (torch.randn(rows, cols, generator=g) * (0.02 if tag == "real" else 1.0))
-                if tag == "coarse":
-                    full_c = (full_c * 2).round() / 2                                   # few magnitudes: huge tie classes, cut inside a rank
-                full_c = full_c.to(torch.bfloat16)
-                full = full_c.to(dev)
-                local = qd.shard_rows(full, world, rank)
-                # structured: no collective in the data path
-                c = _cfg()
-                single = bfp_ops.float_to_bfp_blocked(full, **c, identifier='w')
-                got = qd.float_to_bfp_blocked_sharded(local, rows, gather=True, identifier='w', **c)
-                assert torch.equal(bits(got), bits(single)), ("2:4", rows, cols, tag)
-                # unstructured: one threshold for the whole tensor, ties lowest global flat index first
-                for first in ('s', 'q'):
-                    for frac in (0.5, 0.13):
-                        cu = _cfg(sparsity_mode='unstructured', sparsity_frac=frac, first=first)
-                        single = bfp_ops.float_to_bfp_blocked(full, **cu, identifier='w')
-                        got = qd.float_to_bfp_blocked_sharded(local, rows, gather=True, identifier='w', **cu)
-                        assert torch.equal(bits(got), bits(single)), ("unstructured", rows, cols, tag, first, frac)
-                pruned = qd.all_gather_rows(qd.unstructured_sparsity_sharded(local, 0.5, full.numel()), rows)
-                assert torch.equal(bits(pruned), bits(bfp_ops._unstructured_sparsity(full, 'cuda', 0.5))), ("prune only", rows, cols, tag)
-                if rows % world == 0 and cols % 64 == 0:                                # packed wire format
-                    codes, exps = qd.float_to_bfp_packed_sharded(local, rows, 3, 64, gather=True, N=2, M=4)
-                    c1, e1 = bfp_ops.float_to_bfp_packed(full, 3, 64, N=2, M=4)
-                    assert torch.equal(codes, c1) and torch.equal(exps, e1), ("packed", rows, cols)
+        bits = lambda t: t.contiguous().view(torch.int32 if t.dtype == torch.float32 else torch.int16)      # noqa: E731
+        # rows: even split, ragged split, fewer rows than ranks (empty slabs), the LLaMA-7B q_proj shape; bf16 takes one 15-bit
+        # radix pass, fp32 three (11 + 11 + 9 bits), each with its own histogram all-gather and the prefix carried in the workspace
+        # (OPT and ViT, BASELINE configs 1 and 5, are fp32 models)
+        for dt, shapes in ((torch.bfloat16, ((64, 256), (37, 512), (1, 128), (4096, 4096))),
+                           (torch.float32, ((64, 256), (37, 512), (1, 128), (1024, 3072)))):
+            for rows, cols in shapes:
+                for tag in ("real", "coarse"):
+                    full_c = (torch.randn(rows, cols, generator=g) * (0.02 if tag == "real" else 1.0))
+                    if tag == "coarse":
+                        full_c = (full_c * 2).round() / 2                               # few magnitudes: huge tie classes, cut inside a rank
+                    full_c = full_c.to(dt)
+                    full = full_c.to(dev)
+                    local = qd.shard_rows(full, world, rank)
+                    # structured: no collective in the data path
+                    c = _cfg()
+                    single = bfp_ops.float_to_bfp_blocked(full, **c, identifier='w')
+                    got = qd.float_to_bfp_blocked_sharded(local, rows, gather=True, identifier='w', **c)
+                    assert torch.equal(bits(got), bits(single)), ("2:4", dt, rows, cols, tag)
+                    # unstructured: one threshold for the whole tensor, ties lowest global flat index first
+                    for first in ('s', 'q'):
+                        for frac in (0.5, 0.13):
+                            cu = _cfg(sparsity_mode='unstructured', sparsity_frac=frac, first=first)
+                            single = bfp_ops.float_to_bfp_blocked(full, **cu, identifier='w')
+                            got = qd.float_to_bfp_blocked_sharded(local, rows, gather=True, identifier='w', **cu)
+                            assert torch.equal(bits(got), bits(single)), ("unstructured", dt, rows, cols, tag, first, frac)
+                    pruned = qd.all_gather_rows(qd.unstructured_sparsity_sharded(local, 0.5, full.numel()), rows)
+                    assert torch.equal(bits(pruned), bits(bfp_ops._unstructured_sparsity(full, 'cuda', 0.5))), ("prune only", dt, rows, cols, tag)
+                    if rows % world == 0 and cols % 64 == 0 and dt == torch.bfloat16:   # packed wire format
+                        codes, exps = qd.float_to_bfp_packed_sharded(local, rows, 3, 64, gather=True, N=2, M=4)
+                        c1, e1 = bfp_ops.float_to_bfp_packed(full, 3, 64, N=2, M=4)
+                        assert torch.equal(codes, c1) and torch.equal(exps, e1), ("packed", rows, cols)
+        # BASELINE config 4 at its own shape: a LLaMA-13B q_proj [5120,5120] bf16, 50 % unstructured then HBFP4, row-sharded
+        # (5120 rows: even over 2 ranks, ragged over 3), every rank generating the same tensor on the device
+        gd = torch.Generator(device=dev).manual_seed(13)
+        full = (torch.randn(5120, 5120, generator=gd, device=dev) * 0.02).to(torch.bfloat16)
+        local = qd.shard_rows(full, world, rank)
+        cu = _cfg(sparsity_mode='unstructured', sparsity_frac=0.5, first='s')
+        single = bfp_ops.float_to_bfp_blocked(full, **cu, identifier='w')
+        got = qd.float_to_bfp_blocked_sharded(local, 5120, gather=True, identifier='w', **cu)
+        assert torch.equal(bits(got), bits(single)), "cfg4 [5120,5120] sharded"
+        assert int((got == 0).sum()) >= full.numel() // 2
+        # the overlapped gather (persistent side stream, staging buffer + strided copy) == the plain gather
+        if 5120 % world == 0:
+            c = _cfg()
+            ov = qd.gather_overlapped(local, 5120, lambda p: bfp_ops.float_to_bfp_blocked(p, **c, identifier='w'), chunks=4)
+            assert torch.equal(bits(ov), bits(bfp_ops.float_to_bfp_blocked(full, **c, identifier='w'))), "gather_overlapped"
         torch.cuda.synchronize()
         open(os.path.join(tmpdir, f"ok{rank}"), "w").write("ok")
     finally:

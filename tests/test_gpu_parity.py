@@ -281,7 +281,8 @@ def test_unstructured_fused_and_fallback(shape, dname):
 
 
 # ---- packed output -----------------------------------------------------------------------------
-@pytest.mark.parametrize("dname,m,blk,code_bits", [("bf16", 3, 64, 4), ("f16", 3, 32, 4), ("f32", 7, 16, 8), ("bf16", 7, 64, 8), ("f32", 15, 32, 16)])
+@pytest.mark.parametrize("dname,m,blk,code_bits", [("bf16", 3, 64, 4), ("f16", 3, 32, 4), ("f32", 7, 16, 8), ("bf16", 7, 64, 8), ("f32", 15, 32, 16),
+                                                   ("f16", 3, 64, 4), ("bf16", 2, 64, 4), ("f16", 1, 64, 4), ("bf16", 1, 64, 4)])
 def test_packed_roundtrip(dname, m, blk, code_bits):
     dt = DT[dname]
     xc = synth(512, 1024, dt)
@@ -1121,6 +1122,49 @@ def test_every_block_max_pattern_dropin(dname):
         assert_bits_equal(bits(got), bits(want), dt, f"{dname} m={m} eps={eps}")
     got = bfp_ops._no_sparsity_float_to_bfp(x.view(-1, 16), 16, 3, 1e-8, 'determ', 'cuda')          # other lane-group widths
     assert_bits_equal(bits(got), bits(O.no_sparsity_float_to_bfp(xc.view(-1, 16), 16, 3, 1e-8)), dt, f"{dname} block 16")
+
+
+@pytest.mark.parametrize("dname", ["bf16", "f16"])
+def test_every_block_max_pattern_packed_only(dname):
+    """the packed-only instantiation (4-bit codes + int8 exponents, no dequantised tensor: north_star's "packed int4 stores")
+    over EVERY finite 16-bit magnitude as the block max: codes straight from the signed lean arithmetic (clamp, magic-constant
+    add, low nibble), exponent bytes by the one-lane-per-block byte store, general tiers packed inside their branch -- decoded
+    as code * 2^(e - m), they must equal the oracle's values; dense, 2:4 sparsify-first and 2:4 quantize-first."""
+    dt = DT[dname]
+    hi = 0x7F80 if dname == "bf16" else 0x7C00
+    pat = np.arange(0, hi, dtype=np.uint16)
+    n = pat.size
+    rng = np.random.default_rng(9)
+    blk = np.zeros((n, 64), dtype=np.uint16)
+    blk[:, 0] = pat
+    for j in range(1, 64):
+        drop = rng.integers(0, 40, size=n).astype(np.int64) * (1 << (7 if dname == "bf16" else 10))
+        m_ = np.maximum(pat.astype(np.int64) - drop - rng.integers(0, 128, size=n), 0)
+        blk[:, j] = (m_.astype(np.uint16)) | (rng.integers(0, 2, size=n).astype(np.uint16) << 15)
+    blk[:, 0] |= (rng.integers(0, 2, size=n).astype(np.uint16) << 15)
+    blk[:, [0, 37]] = blk[:, [37, 0]]
+    xc = from_bits(blk.reshape(-1), dt).view(n, 64)
+    x = xc.to(DEV)
+    for m in (3, 2, 1):
+        for N, M, first in ((0, 0, 's'), (2, 4, 's'), (2, 4, 'q')):
+            codes, exps = bfp_ops.float_to_bfp_packed(x, m, 64, N=N, M=M, first=first, code_bits=4)
+            c = cfg(mant_bits=m, block_size=64, w_sparsity=N > 0, N=N or 2, M=M or 4, first=first)
+            want = O.float_to_bfp_blocked(xc, **c, identifier='w').to(torch.float64)
+            cc = codes.cpu()
+            q = torch.stack([(cc & 0xF).to(torch.int16), (cc >> 4).to(torch.int16)], dim=-1).view(n, 64)
+            q = torch.where(q > 7, q - 16, q).to(torch.float64)
+            e = exps.cpu().to(torch.float64).view(n, 1)
+            val = q * torch.pow(torch.tensor(2.0, dtype=torch.float64), e - m)
+            nanblk = exps.cpu().view(n) == -128                               # the reference's NaN blocks (fp16: zero block)
+            ok = torch.isnan(want).any(dim=1) == nanblk                        # (quantize-first: pruning after it zeroes part of a NaN block)
+            assert bool(ok.all()), (dname, m, N, first, "NaN-block markers")
+            good = ~nanblk
+            sat = (exps.cpu().view(n).abs() == 127) & good                     # exponents beyond int8: the byte saturates, values are lost by design
+            good &= ~sat
+            good &= ~torch.isinf(want).any(dim=1)                              # fp16 block max >= 61440: the reference's 2^16 overflows to inf and so
+                                                                               # do its top values (code 8 x 2^13); a 4-bit code cannot say "inf"
+            assert torch.equal(val[good], want[good]), (dname, m, N, first, int((val[good] != want[good]).sum()))
+            assert int((q.abs() > (1 << m) - 1).sum()) == 0
 
 
 @pytest.mark.parametrize("dname", ["bf16", "f16", "f32"])

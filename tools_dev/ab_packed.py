@@ -1,0 +1,51 @@
+"""A/B harness for the packed-output kernel: several builds of libbfpq.so in ONE process, interleaved rounds, hipGraph of L
+launches each ([4096,11008] bf16, 2:4 -> HBFP4, 4-bit codes + int8 exponents only).
+usage: python tools_dev/ab_packed.py name=path.so ..."""
+import ctypes, sys, statistics, torch
+sys.path.insert(0, '.')
+from quantization_sparsity_interplay_amd import native
+rows, cols, L, R, ROUNDS = 4096, 11008, 100, 8, 10
+dev = torch.device('cuda:0')
+libs = {}
+for a in sys.argv[1:]:
+    n, p = a.split('=')
+    tune = None
+    if '@' in p:                                   # name=path.so@grid : bfpq_tune(BFPQ_TUNE_MAX_GRID, grid) in that library
+        p, tune = p.split('@')
+    lib = ctypes.CDLL(p)
+    if tune:
+        import shutil, tempfile
+        q = tempfile.mktemp(suffix=f"_{n}.so"); shutil.copy(p, q); lib = ctypes.CDLL(q)      # (a private copy: its own tuning global)
+        assert lib.bfpq_tune(0, int(tune)) == 0
+    vp, i64, i32, u64, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint64, ctypes.c_double
+    lib.bfpq_quantize_nm.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, dbl, i32, i32, i32, i32, u64, vp, vp, vp, vp]
+    lib.bfpq_quantize_nm.restype = i32
+    libs[n] = lib
+ins = [(torch.randn(rows, cols, generator=torch.Generator().manual_seed(r)) * 0.02).to(torch.bfloat16).to(dev) for r in range(R)]
+codes = [torch.empty(rows, cols // 2, dtype=torch.uint8, device=dev) for _ in range(R)]
+exps = [torch.empty(rows, cols // 64, dtype=torch.int8, device=dev) for _ in range(R)]
+win = native.exp_window_dev(torch.bfloat16, dev); lut = native.nm4_lut_dev(2, dev)
+graphs = {}
+for n, lib in libs.items():
+    def run():
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for i in range(L):
+            rc = lib.bfpq_quantize_nm(ins[i % R].data_ptr(), None, codes[i % R].data_ptr(), exps[i % R].data_ptr(), rows, cols, 2, 64, 3, 1e-8, 2, 4, 1, 4, 0,
+                                      win.data_ptr(), lut.data_ptr(), None, st)
+            assert rc == 0, rc
+    run(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        run()
+    g.replay(); torch.cuda.synchronize()
+    graphs[n] = g
+times = {n: [] for n in libs}
+for r in range(ROUNDS):
+    for n, g in graphs.items():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        times[n].append(e0.elapsed_time(e1) * 1e3 / L)
+bytes_ = rows * cols * (2 + 0.5 + 1 / 64)
+for n, t in times.items():
+    med, mn = statistics.median(t), min(t)
+    print(f"{n:12s} median {med:6.2f} us  min {mn:6.2f} us  -> {bytes_/med/1e3:7.1f} GB/s median ({bytes_/med/1e3/8000*100:4.1f}% of 8 TB/s)")
