@@ -308,7 +308,8 @@ typedef struct bfpq_select_state {
     uint32_t cut_lo;      /* this device's elements equal to tau go in lane items (16 B) [0, cut_lo), stay in [cut_hi, end), */
     uint32_t cut_hi;      /* and inside [cut_lo, cut_hi) -- one segment of the histogram launch, or empty -- the first        */
     uint32_t cut_within;  /* cut_within of them (flat order) go                                                              */
-    uint32_t reserved[2];
+    uint32_t cut_total;   /* elements equal to tau inside [cut_lo, cut_hi)                                                   */
+    uint32_t reserved;
 } bfpq_select_state;
 
 #ifdef __cplusplus

@@ -220,7 +220,7 @@ constexpr int kMaxSeg = BFPQ_SELECT_MAX_SEGMENTS;
 constexpr int kWinBins = BFPQ_SELECT_WINDOW_BINS;
 constexpr int kFineBins = 32768, kCoarseBins = 256;
 constexpr int kResItems = 13;                 // lane items a thread of the resident kernel holds (13 x 1024 x 256 x 16 B = 54.5 MB per tensor)
-constexpr int kCutWGs = 32;                   // workgroups of the apply launch that own the cut segment (dispatched first)
+constexpr int kCutWGs = 64;                   // workgroups of the apply launch that own the cut segment (dispatched first)
 
 struct SelWs {
     bfpq_select_state st;
@@ -278,6 +278,7 @@ struct ThrCtx {
     bool on;
     int64_t cut_lo, cut_hi;    // the cut segment in lane items (multiples of 64; cut_hi possibly n_items); empty: no tile is ranked
     uint32_t within;           // ties to prune inside the cut segment, counted from its start
+    uint32_t cut_total;        // ties inside the cut segment
     // per tile:
     uint32_t teff;             // ordinary workgroups: prune keys below this (tau + 1 in front of the cut segment, tau behind it)
     bool ranked;               // cut workgroups: the ties of this tile are ranked ...
@@ -297,7 +298,7 @@ template <int DT> __device__ __forceinline__ uint32_t count_eq(const uint32_t* r
 }
 
 // where the cut lies for a tensor whose per-segment tie counts are v[0..G) (one per thread, 0 beyond G): the three numbers
-// the apply launch needs.  Block-uniform result through s_res (3 words); uses block_excl_scan's barriers.
+// the apply launch needs (+ the cut segment's own tie count).  Block-uniform result through s_res (4 words); uses block_excl_scan's barriers.
 //   need_local: ties of THIS device to prune (need - tie_base); total: this device's ties
 __device__ __forceinline__ void cut_from_seg_ties(uint32_t v, int64_t need_local, const SegGeom& g, int64_t n_items, uint32_t* s_part, uint32_t* s_res)
 {
@@ -306,13 +307,13 @@ __device__ __forceinline__ void cut_from_seg_ties(uint32_t v, int64_t need_local
     const int tid = threadIdx.x;
     const uint32_t n_round = (uint32_t)((n_items + 63) / 64 * 64);
     if (tid == 0) {
-        if (need_local <= 0) { s_res[0] = 0; s_res[1] = 0; s_res[2] = 0; }                         // no tie goes
-        else if (need_local >= (int64_t)total) { s_res[0] = n_round; s_res[1] = n_round; s_res[2] = 0; }   // every tie goes
+        if (need_local <= 0) { s_res[0] = 0; s_res[1] = 0; s_res[2] = 0; s_res[3] = 0; }                         // no tie goes
+        else if (need_local >= (int64_t)total) { s_res[0] = n_round; s_res[1] = n_round; s_res[2] = 0; s_res[3] = 0; }   // every tie goes
     }
     if (need_local > 0 && need_local < (int64_t)total && v && (int64_t)excl <= need_local && need_local < (int64_t)excl + v) {
         const int64_t b0 = (int64_t)tid * g.L, b1 = b0 + g.L < n_items ? b0 + g.L : n_items;
         const uint32_t within = (uint32_t)(need_local - excl);
-        s_res[0] = (uint32_t)b0; s_res[1] = within ? (uint32_t)b1 : (uint32_t)b0; s_res[2] = within;
+        s_res[0] = (uint32_t)b0; s_res[1] = within ? (uint32_t)b1 : (uint32_t)b0; s_res[2] = within; s_res[3] = v;
     }
     __syncthreads();
 }
@@ -337,11 +338,11 @@ __device__ __forceinline__ void thr_setup(ThrCtx& t, SelWs* ws, int64_t n_items,
     }
     t.tau = st->tau;
     t.on = st->k > 0;
-    t.cut_lo = t.cut_hi = 0; t.within = 0;                   // empty cut segment at the front: no tie is pruned
+    t.cut_lo = t.cut_hi = 0; t.within = 0; t.cut_total = 0;  // empty cut segment at the front: no tie is pruned
     t.teff = 0; t.ranked = false; t.before = 0;
     t.dump = reinterpret_cast<uint4*>(ws->windows);
     if (!t.on) { t.tau = 0; return; }                        // (k == 0: nothing is below a threshold of 0)
-    if (flags & 1u) { t.cut_lo = st->cut_lo; t.cut_hi = st->cut_hi; t.within = st->cut_within; return; }
+    if (flags & 1u) { t.cut_lo = st->cut_lo; t.cut_hi = st->cut_hi; t.within = st->cut_within; t.cut_total = st->cut_total; return; }
     // the resolve launch had to recount some segments (window miss): their tie counts are in seg_ties
     const int64_t need = st->need, ties = st->ties;
     const uint32_t n_round = (uint32_t)((n_items + 63) / 64 * 64);
@@ -350,7 +351,7 @@ __device__ __forceinline__ void thr_setup(ThrCtx& t, SelWs* ws, int64_t n_items,
     const SegGeom g = seg_geom(n_items);
     const uint32_t v = (int)threadIdx.x < g.G ? ws->seg_ties[threadIdx.x] : 0u;
     cut_from_seg_ties(v, need - st->tie_base, g, n_items, s_part, s_res);
-    t.cut_lo = s_res[0]; t.cut_hi = s_res[1]; t.within = s_res[2];
+    t.cut_lo = s_res[0]; t.cut_hi = s_res[1]; t.within = s_res[2]; t.cut_total = s_res[3];
 }
 
 // prune bits of one lane item of a RANKED tile (bit j = element j goes): everything below tau, and the ties whose rank
@@ -391,10 +392,13 @@ __device__ __forceinline__ void cut_wg_run(const ThrCtx& t, const void* in, int6
     const int64_t T = (nB + kCutWGs - 1) / kCutWGs;
     const int64_t g0 = (int64_t)blockIdx.x * T, g1 = g0 + T < nB ? g0 + T : nB;
     if (g0 >= g1) return;                                                    // (block-uniform)
+    // ties in front of this workgroup's first tile: counted from whichever end of the segment is nearer (the segment's total is
+    // known), so the longest count is half a segment -- the last workgroups' counts were the tail of the whole launch on large tensors
     uint32_t c = 0;
+    const bool from_end = 2 * g0 > nB;
     {
-        int64_t it = t.cut_lo + tid;
-        const int64_t end = t.cut_lo + g0 * 64;
+        int64_t it = (from_end ? t.cut_lo + g0 * 64 : t.cut_lo) + tid;
+        const int64_t end = from_end ? (t.cut_hi < n_items ? t.cut_hi : n_items) : t.cut_lo + g0 * 64;
         for (; it + 7 * 256 < end; it += 8 * 256) {
             uint32_t r[8][VEC];
 #pragma unroll
@@ -412,6 +416,7 @@ __device__ __forceinline__ void cut_wg_run(const ThrCtx& t, const void* in, int6
     if (lane == 0) s_x[wave] = c;
     __syncthreads();
     uint32_t running = s_x[0] + s_x[1] + s_x[2] + s_x[3];
+    if (from_end) running = t.cut_total - running;
     for (int64_t g = g0; g < g1; g += 4) {                                   // (block-uniform trip count)
         const int64_t tile = g + wave;
         const bool active = tile < g1;

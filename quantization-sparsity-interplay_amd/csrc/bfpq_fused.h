@@ -814,7 +814,7 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
         __syncthreads();
         if (!s_pub[7]) return;                                   // (gave up: this segment's output is missing, ws->error says so)
         thr.tau = s_pub[0]; thr.on = s_pub[1] != 0; thr.cut_lo = s_pub[2]; thr.cut_hi = s_pub[3]; thr.within = s_pub[4];
-        thr.teff = 0; thr.ranked = false; thr.before = 0; thr.dump = reinterpret_cast<uint4*>(ws->windows);
+        thr.teff = 0; thr.ranked = false; thr.before = 0; thr.cut_total = 0; thr.dump = reinterpret_cast<uint4*>(ws->windows);
         if (!thr.on) thr.tau = 0;
         const bool cut_seg = thr.on && i0 >= thr.cut_lo && i0 < thr.cut_hi;      // (the cut segment is exactly one segment of this geometry)
         if (cut_seg) {

@@ -239,13 +239,14 @@ __device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int
         const uint32_t incl = wave_incl_scan(mine), excl = incl - mine;
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         const uint32_t n_round = (uint32_t)((n_items + 63) / 64 * 64);
-        uint32_t lo = 0, hi = 0, within = 0;
+        uint32_t lo = 0, hi = 0, within = 0, ctot = 0;
         if (need >= total && need > 0) { lo = hi = n_round; }            // every tie goes ((need == 0: none does)
         else if (need > 0) {
             const bool hit = mine && excl <= need && need < excl + mine;
             uint32_t seg = 4u * lane, e = excl;
             if (need >= e + v[0]) { e += v[0]; seg++; if (need >= e + v[1]) { e += v[1]; seg++; if (need >= e + v[2]) { e += v[2]; seg++; } } }
             const uint32_t B = pick_lane(hit, seg), w0 = pick_lane(hit, need - e);
+            ctot = pick_lane(hit, seg == 4u * lane ? v[0] : (seg == 4u * lane + 1 ? v[1] : (seg == 4u * lane + 2 ? v[2] : v[3])));
             const int64_t b0 = (int64_t)B * g.L, b1 = b0 + g.L < n_items ? b0 + g.L : n_items;
             lo = (uint32_t)b0; hi = w0 ? (uint32_t)b1 : (uint32_t)b0; within = w0;
         }
@@ -254,8 +255,8 @@ __device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int
             bfpq_select_state* st = &ws->st;
             st->prefix = tau; st->prefix_mask = 0x7fffu; st->k_rem = (int64_t)need; st->tau = tau; st->done = 1;
             st->need = (int64_t)need; st->ties = (int64_t)ties; st->k = k; st->tie_base = 0;
-            st->flags = 1u; st->cut_lo = lo; st->cut_hi = hi; st->cut_within = within;
-            st->reserved[0] = st->reserved[1] = 0;
+            st->flags = 1u; st->cut_lo = lo; st->cut_hi = hi; st->cut_within = within; st->cut_total = ctot;
+            st->reserved = 0;
             ws->ticket = 0u;                                     // ready for the next call
             if (publish) {
                 // the resident kernel's other workgroups are waiting for exactly these words: write-through stores, drained, then

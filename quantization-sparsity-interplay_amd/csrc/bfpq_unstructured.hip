@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(kResThreads) k_select_resolve(const void* in, 
         st->need = (int64_t)need; st->ties = (int64_t)cnt; st->k = k0;
         st->tie_base = (int64_t)tie_base; st->flags = (any_miss ? 0u : 1u) | (own_hist ? 2u : 0u);
         st->cut_lo = any_miss ? 0u : s_res[8]; st->cut_hi = any_miss ? 0u : s_res[9]; st->cut_within = any_miss ? 0u : s_res[10];
-        st->reserved[0] = st->reserved[1] = 0;
+        st->cut_total = any_miss ? 0u : s_res[11]; st->reserved = 0;
     }
 }
 

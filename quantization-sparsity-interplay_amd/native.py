@@ -453,9 +453,9 @@ class SelectWorkspace:
         """host copy of bfpq_select_state (synchronises; for tests / diagnostics only)"""
         import struct
         raw = self.ws[:SELECT_STATE_BYTES // 8].cpu().numpy().tobytes()
-        prefix, mask, k_rem, tau, done, need, ties, k, tie_base, flags, cut_lo, cut_hi, cut_within = struct.unpack_from("<IIqIIqqqqIIII", raw, 0)
+        prefix, mask, k_rem, tau, done, need, ties, k, tie_base, flags, cut_lo, cut_hi, cut_within, cut_total = struct.unpack_from("<IIqIIqqqqIIIII", raw, 0)
         return dict(prefix=prefix, prefix_mask=mask, k_rem=k_rem, tau=tau, done=done, need=need, ties=ties, k=k,
-                    tie_base=tie_base, flags=flags, cut_lo=cut_lo, cut_hi=cut_hi, cut_within=cut_within)
+                    tie_base=tie_base, flags=flags, cut_lo=cut_lo, cut_hi=cut_hi, cut_within=cut_within, cut_total=cut_total)
 
 
 def select_threshold(t, k, ws, numel_global=None, allgather=None):

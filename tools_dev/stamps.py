@@ -18,6 +18,8 @@ x = xs[0]
 L = native.load_library()
 ws = bfp_ops._workspace(x.device)
 resident = os.environ.get("RESIDENT", "0") == "1"
+if resident:
+    assert L.bfpq_tune(3, 1) == 0
 outs = [torch.empty_like(x) for x in xs]
 for i in range(3 * len(xs) + 1):                  # (rotating inputs and outputs: neither L2 nor the Infinity Cache serves the stream)
     x = xs[i % len(xs)]
