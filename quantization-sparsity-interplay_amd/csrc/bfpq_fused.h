@@ -489,16 +489,13 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
             }
             if constexpr (!GUARD) {
                 // (32-bit byte offsets from a uniform base: one shift per address; the launcher cuts tensors beyond 2^28 items)
-#if !defined(BFPQ_AB) || BFPQ_AB != 2
+                // (A/B on one box, tools_dev/ab_packed.py: without the code stores 22.3 us, without the exponent stores no change,
+                //  non-temporal code stores +0.7 us, three sweeps of loads ahead instead of two +1.3 us)
                 if constexpr (MX8) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(a.out_codes) + (uint32_t)item * 8u) = make_uint2(pack_w, pack_w2);
                 else *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.out_codes) + (uint32_t)item * 4u) = pack_w;
-#else
-                if (pack_w == 0x12345u && pack_e == 77) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(a.out_codes) + (uint32_t)item * 4u) = pack_w;   // (A/B: no code stores)
-#endif
                 // the block's exponent byte: ONE byte store per wave-instruction with only the first lane of each block enabled
                 // (exec narrowed around it by hand -- a branch would make hipcc drain the memory queue at the loop top; the eight
                 // v_readlane + scalar packing this replaces cost 9 vector instructions per item)
-#if !defined(BFPQ_AB) || BFPQ_AB != 1
                 {
                     unsigned long long saved;
                     const unsigned long long lead = 0x0101010101010101ull;
@@ -506,9 +503,6 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
                     asm volatile("s_and_saveexec_b64 %0, %4\n\tglobal_store_byte %1, %2, %3\n\ts_mov_b64 exec, %0"
                                  : "=&s"(saved) : "v"(eoff), "v"(pack_e), "s"(a.out_exp), "s"(lead) : "memory");                 // (exec is restored inside)
                 }
-#else
-                if (pack_e == 12345) a.out_exp[item >> 3] = (int8_t)pack_e;        // (A/B: no exponent stores)
-#endif
             } else if (valid) {
                 if constexpr (MX8) reinterpret_cast<uint2*>(a.out_codes)[item] = make_uint2(pack_w, pack_w2);
                 else reinterpret_cast<uint32_t*>(a.out_codes)[item] = pack_w;
@@ -1087,7 +1081,7 @@ int launch_fused_mx8(const FusedArgs& a, hipStream_t s)
             b.out_codes = reinterpret_cast<char*>(a.out_codes) + i0 * 8;
             b.out_exp = a.out_exp + i0 / 8;
             b.n_items = a.n_items - i0 < piece ? a.n_items - i0 : piece;
-            const dim3 grid(grid_for_packed(b.n_items)), block(kThreads);
+            const dim3 grid(grid_for_cap(b.n_items, (int64_t)kMaxGrid * 43 / 16)), block(kThreads);       // (the image writes twice the codes' bytes: 2752 measured best, 14.3 vs 14.8 us at 2048)
             hipLaunchKernelGGL((k_fused_flat<DT, 0, true, false, 8, false, false, 8>), grid, block, 0, s, b);
         }
         return (int)hipGetLastError();

@@ -562,6 +562,7 @@ class PruneQuantizeList:
     ks: elements to prune per tensor, int(numel * frac) as the reference computes it (bfp_ops.py:66)."""
 
     N_WS = 4
+    GRAPH_FROM = 8           # lists of at least this many tensors replay a hipGraph of the pipeline (captured on the first run)
 
     def __init__(self, tensors, ks, block_size, mant_bits, epsilon, outs=None):
         tensors = list(tensors)
@@ -595,8 +596,22 @@ class PruneQuantizeList:
                 self._win = exp_window_dev(self.dtype, self.device)
                 self._aux = aux_stream(self.device)
         self._fn = load_library().bfpq_prune_quantize_batched
+        self._graph = None
 
-    def run(self, pipelined=True):
+    def _issue(self, pipelined):
+        dev = self.device
+        with torch.cuda.device(dev):
+            rc = self._fn(ctypes.addressof(self._descs), self._n, DTYPE_CODE[self.dtype], self.block_size, self.mant_bits, self.epsilon,
+                          self._win.data_ptr(), ctypes.addressof(self._ws_ptrs), self.N_WS, torch.cuda.current_stream(dev).cuda_stream,
+                          self._aux.cuda_stream if pipelined else None)
+        if rc:
+            check(rc, "bfpq_prune_quantize_batched")
+
+    def run(self, pipelined=True, graph=None):
+        """graph: replay a hipGraph of the whole pipeline (captured on the first such run; every pointer in it is bound --
+        a tensor whose storage moved drops the graph).  Default: for lists of GRAPH_FROM tensors or more, outside any
+        capture already in progress.  The ~6 host calls per tensor (2 launches, 4 event operations) otherwise cost more
+        host time than a small tensor's launches take on the device."""
         if self._n:
             for j, (t, ptr, n) in enumerate(self._bound):                 # follow tensors whose storage moved (see PreparedList)
                 cur = t.data_ptr()
@@ -605,13 +620,20 @@ class PruneQuantizeList:
                         raise RuntimeError("PruneQuantizeList: a bound tensor changed dtype / device / size / layout since it was bound; build a new list")
                     self._descs[j].in_dev = cur
                     self._bound[j] = (t, cur, n)
-            dev = self.device
-            with torch.cuda.device(dev):
-                rc = self._fn(ctypes.addressof(self._descs), self._n, DTYPE_CODE[self.dtype], self.block_size, self.mant_bits, self.epsilon,
-                              self._win.data_ptr(), ctypes.addressof(self._ws_ptrs), self.N_WS, torch.cuda.current_stream(dev).cuda_stream,
-                              self._aux.cuda_stream if pipelined else None)
-            if rc:
-                check(rc, "bfpq_prune_quantize_batched")
+                    self._graph = None
+            if graph is None:
+                graph = self._n >= self.GRAPH_FROM
+            if graph and pipelined and not torch.cuda.is_current_stream_capturing():
+                if self._graph is None:
+                    self._issue(True)                                     # (warm-up outside the capture)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.device(self.device), torch.cuda.graph(g):
+                        self._issue(True)
+                    self._graph = g
+                with torch.cuda.device(self.device):
+                    self._graph.replay()
+            else:
+                self._issue(pipelined)
         return self.outputs
 
 

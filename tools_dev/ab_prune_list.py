@@ -51,12 +51,13 @@ for res in (0, 1):
 assert L.bfpq_tune(3, 0) == 0
 if os.environ.get("SINGLE_ONLY"):
     sys.exit(0)
-for name, fn in (("serial eager", lambda: pl.run(pipelined=False)), ("pipelined eager", lambda: pl.run(pipelined=True))):
+for name, fn in (("serial eager", lambda: pl.run(pipelined=False, graph=False)), ("pipelined eager", lambda: pl.run(pipelined=True, graph=False)),
+                 ("pipelined, own hipGraph", lambda: pl.run())):
     us = timed(fn)
     print(f"{name:24s} {us/1e3:8.2f} ms  {numel*4/us/1e3:7.0f} GB/s on 4 B/elem ({numel*4/us/80e3:5.1f} %)  {numel*6/us/80e3:5.1f} % on the two-read 6 B/elem", flush=True)
 for name, pipe in (("serial hipGraph", False), ("pipelined hipGraph", True)):
     gr = torch.cuda.CUDAGraph()
     with torch.cuda.graph(gr):
-        pl.run(pipelined=pipe)
+        pl.run(pipelined=pipe, graph=False)
     us = timed(gr.replay)
     print(f"{name:24s} {us/1e3:8.2f} ms  {numel*4/us/1e3:7.0f} GB/s on 4 B/elem ({numel*4/us/80e3:5.1f} %)  {numel*6/us/80e3:5.1f} % on the two-read 6 B/elem", flush=True)
