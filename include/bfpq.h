@@ -49,8 +49,6 @@ int bfpq_version(void);
 #define BFPQ_TUNE_MAX_GRID 0       /* cap on workgroups of the streaming kernels (default 1024) */
 #define BFPQ_TUNE_GEMM_ROW_TILES 1 /* 16-row tiles per wave in bfpq_hbfp_linear_decode_tiled: 0 = choose (default), 1, 2, 4 */
 #define BFPQ_TUNE_MX8_VARIANT 2    /* tile shape of bfpq_hbfp_linear_mx8: -1 = choose (default), 0..6 force (A/B measurements) */
-#define BFPQ_TUNE_RESIDENT 3       /* bfpq_prune_quantize: 1 = use the resident one-read kernel where it applies, 0 = always the two launches (default: measured faster) */
-#define BFPQ_TUNE_RESIDENT_TIMEOUT_US 4 /* how long a workgroup of the resident kernel waits for the resolved threshold (default 200000) */
 int bfpq_tune(int key, int value);
 const char* bfpq_error_string(int code);
 
@@ -163,7 +161,7 @@ int bfpq_nm_sparsify(const void* in_dev, void* out_dev, int64_t rows, int64_t co
 #define BFPQ_SELECT_WINDOW_BINS 2048
 #define BFPQ_SELECT_HIST_ENTRIES (32768 + 256)   /* fine bins, then (16-bit dtypes) 256 coarse bins of 128 */
 #define BFPQ_SELECT_HIST_COPIES 8                /* a device accumulates into 8 copies (cuts the contention of the flush) */
-#define BFPQ_SELECT_WS_BYTES (BFPQ_SELECT_STATE_BYTES + 4 * (44 + BFPQ_SELECT_HIST_COPIES * 256 + 3 * BFPQ_SELECT_HIST_COPIES * BFPQ_SELECT_HIST_ENTRIES + \
+#define BFPQ_SELECT_WS_BYTES (BFPQ_SELECT_STATE_BYTES + 4 * (12 + BFPQ_SELECT_HIST_COPIES * 256 + 3 * BFPQ_SELECT_HIST_COPIES * BFPQ_SELECT_HIST_ENTRIES + \
                               2 * BFPQ_SELECT_MAX_SEGMENTS + BFPQ_SELECT_MAX_SEGMENTS * BFPQ_SELECT_WINDOW_BINS))
 
 int bfpq_select_passes(int dtype);
@@ -186,16 +184,8 @@ int bfpq_quantize_threshold(const void* in_dev, void* out_deq_dev, void* out_cod
                             void* ws_dev, void* scratch_dev, void* stream);
 
 /* The whole s-first unstructured drop-in op, out = Q(S_unstructured(in)) with k = int(numel * frac) elements pruned
- * (float_to_bfp_blocked with sparsity_mode 'unstructured', first 's': bfp_ops.py:61-71, :141-144), single device, round-half-even.
- * Chooses between
- *   - the RESIDENT kernel (16-bit dtypes, block 32 / 64, cols % block == 0, tensor <= 13 x 1024 x 256 lane items = 54.5 MB, at least
- *     as many compute units as segments): ONE launch, the tensor is read ONCE.  One workgroup per segment holds its segment
- *     in registers, histograms it, the last workgroup to publish resolves the threshold, the others wait for it -- the whole grid
- *     is resident by construction (one 1024-thread workgroup with a 128 KB histogram per compute unit), the wait is bounded
- *     (BFPQ_TUNE_RESIDENT_TIMEOUT_US), and a workgroup that gives up stores nothing and sets the error word that
- *     bfpq_select_error() reads -- then prunes + quantizes from registers; and
- *   - bfpq_select + bfpq_quantize_threshold (two launches, two reads) for everything else.
- * Same result either way. */
+ * (float_to_bfp_blocked with sparsity_mode 'unstructured', first 's': bfp_ops.py:61-71, :141-144), single device, round-half-even:
+ * bfpq_select + bfpq_quantize_threshold behind one call (two launches for a 16-bit dtype; the tensor is read by both). */
 int bfpq_prune_quantize(const void* in_dev, void* out_dev, int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits,
                         double epsilon, int64_t k, const uint8_t* exp_win_dev, void* ws_dev, void* stream);
 /* The same op for a LIST of tensors -- every Linear weight of a model (BASELINE config 4) -- pipelined over two streams: the
@@ -208,10 +198,6 @@ int bfpq_prune_quantize(const void* in_dev, void* out_dev, int64_t rows, int64_t
 typedef struct bfpq_prune_desc { const void* in_dev; void* out_dev; int64_t rows, cols; int64_t k; } bfpq_prune_desc;
 int bfpq_prune_quantize_batched(const bfpq_prune_desc* descs_host, int n, int dtype, int block_size, int mant_bits, double epsilon,
                                 const uint8_t* exp_win_dev, void* const* ws_devs_host, int n_ws, void* stream, void* aux_stream);
-/* 1 if bfpq_prune_quantize would take the resident kernel for this problem on the current device */
-int bfpq_prune_quantize_is_resident(const void* in_dev, void* out_dev, int64_t rows, int64_t cols, int dtype, int block_size);
-/* reads (synchronising the stream) and clears the error word of a workspace: non-zero if a resident launch gave up waiting */
-int bfpq_select_error(void* ws_dev, void* stream);
 
 /* ---- 'int' per-channel format (replaces _quantize's 'int' branch, bfp_ops.py:111-120, i.e.
  * int_ops.Quantizer.configure/find_params/quantize with the defaults perchannel=True, sym=True) -------

@@ -244,7 +244,7 @@ def float_to_bfp_blocked(t, mant_bits, epsilon, rounding_mode, device, block_siz
         mb = weight_mant_bits if sgd_update else mant_bits
         ws = _workspace(t.device)
         if rounding_mode == rounding_modes.DETERM:
-            # one entry point: the resident one-read kernel where it applies, else selection launch + fused apply launch
+            # one entry point: selection launch + fused prune + quantize launch
             return native.prune_quantize(t, k, ws, block_size, mb, epsilon).view(t.shape)
         native.select_threshold(t, k, ws)
         y, _, _ = native.quantize_threshold(t, ws, block_size, mb, epsilon, stoch_seed=_seed_for(rounding_mode))

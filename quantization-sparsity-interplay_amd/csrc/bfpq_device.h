@@ -144,9 +144,6 @@ BFPQ_HIDDEN int fused_launch_2(const FusedArgs& a, int M, bool sfirst, hipStream
 BFPQ_HIDDEN int fused_threshold_0(const FusedArgs& a, hipStream_t s);
 BFPQ_HIDDEN int fused_threshold_1(const FusedArgs& a, hipStream_t s);
 BFPQ_HIDDEN int fused_threshold_2(const FusedArgs& a, hipStream_t s);
-BFPQ_HIDDEN int fused_resident_0(const FusedArgs& a, int64_t k, uint32_t timeout_ticks, hipStream_t s);
-BFPQ_HIDDEN int fused_resident_1(const FusedArgs& a, int64_t k, uint32_t timeout_ticks, hipStream_t s);
-BFPQ_HIDDEN int fused_resident_2(const FusedArgs& a, int64_t k, uint32_t timeout_ticks, hipStream_t s);
 BFPQ_HIDDEN int fused_mx8_0(const FusedArgs& a, hipStream_t s);
 BFPQ_HIDDEN int fused_mx8_1(const FusedArgs& a, hipStream_t s);
 BFPQ_HIDDEN int fused_mx8_2(const FusedArgs& a, hipStream_t s);
@@ -160,10 +157,6 @@ inline int fused_launch(int dtype, const FusedArgs& a, int M, bool sfirst, hipSt
 inline int fused_threshold(int dtype, const FusedArgs& a, hipStream_t s)
 {
     return dtype == BFPQ_F32 ? fused_threshold_0(a, s) : (dtype == BFPQ_F16 ? fused_threshold_1(a, s) : fused_threshold_2(a, s));
-}
-inline int fused_resident(int dtype, const FusedArgs& a, int64_t k, uint32_t timeout_ticks, hipStream_t s)
-{
-    return dtype == BFPQ_F32 ? fused_resident_0(a, k, timeout_ticks, s) : (dtype == BFPQ_F16 ? fused_resident_1(a, k, timeout_ticks, s) : fused_resident_2(a, k, timeout_ticks, s));
 }
 inline int fused_mx8(int dtype, const FusedArgs& a, hipStream_t s)
 {
@@ -219,17 +212,12 @@ constexpr int kSelThreads = 1024;
 constexpr int kMaxSeg = BFPQ_SELECT_MAX_SEGMENTS;
 constexpr int kWinBins = BFPQ_SELECT_WINDOW_BINS;
 constexpr int kFineBins = 32768, kCoarseBins = 256;
-constexpr int kResItems = 13;                 // lane items a thread of the resident kernel holds (13 x 1024 x 256 x 16 B = 54.5 MB per tensor)
 constexpr int kCutWGs = 64;                   // workgroups of the apply launch that own the cut segment (dispatched first)
 
 struct SelWs {
     bfpq_select_state st;
     uint32_t ticket;                          // fused histogram + resolve launch: workgroups that have published their segment
-    uint32_t error;                           // resident kernel: set when a workgroup gave up waiting for the epoch (its output is missing)
-    uint32_t pad_[2];
-    uint32_t res_pub[8];                      // resident kernel: {tau, k > 0, cut_lo, cut_hi, cut_within} for the waiting workgroups
-    uint32_t epoch[32];                       // resident kernel: [0] is bumped by the resolving workgroup once res_pub is in memory; a 128-byte
-                                              // line of its own: up to 255 workgroups poll it while the late ones still draw tickets
+    uint32_t pad_[11];
     uint32_t coarse[BFPQ_SELECT_HIST_COPIES][kCoarseBins];   // fused launch: coarse histogram (256 bins of 128), zero between calls
     // histogram buffers of the launch-pair path (fp32; diagnostics), one per radix pass; all zero between calls: the APPLY launch
     // clears what the histogram launches of its call dirtied (see thr_setup; bfpq_select_reset after a select with no apply)

@@ -5,7 +5,6 @@
 #include <type_traits>
 #include "bfpq_quant_math.h"
 #include "nm_select.h"
-#include "bfpq_select.h"
 
 namespace bfpq_dev {
 
@@ -18,9 +17,8 @@ namespace bfpq_dev {
 //   wider than the dtype) makes the whole wavefront replay that item through the step-by-step
 //   emulation (quant_elem); the branch is wave-uniform and never taken on ordinary weights.
 // ---------------------------------------------------------------------------------------------
-template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY, bool BATCHED, bool F32IMG = false, int PACK = 0, int RES = 0>
-__device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unused]] const BatchArgs* b, [[maybe_unused]] int64_t res_k = 0,
-                                                [[maybe_unused]] uint32_t res_timeout = 0)
+template <int DT, int NM, bool SFIRST, bool STOCH, int LPBT, bool DEQ_ONLY, bool BATCHED, bool F32IMG = false, int PACK = 0>
+__device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unused]] const BatchArgs* b)
 {
     using T = Traits<DT>;
     constexpr int VEC = T::VEC;
@@ -730,131 +728,6 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
 #endif
         return;
     }
-    if constexpr (RES > 0) {
-        // ---------------------------------------------------------------------------------------------------------------
-        // RESIDENT form of the unstructured path (NM == -1, 16-bit dtypes, one workgroup of 1024 threads per segment and
-        // compute unit, the whole grid resident): the segment is read ONCE into registers (RES lane items per thread), its
-        // histogram goes the way of the histogram launch (bfpq_select.h: LDS histogram, published window, ticket, the last
-        // workgroup resolves), the workgroups wait -- bounded -- for the resolved threshold, then prune + quantize what they
-        // hold and store it.  2 B read + 2 B written per element instead of 2 + 2 + 2.  The cut segment's workgroup ranks its
-        // ties from its own registers.
-        // A workgroup whose wait runs out (the grid was not resident after all) stores nothing and raises ws->error.
-        // ---------------------------------------------------------------------------------------------------------------
-        static_assert(NM == -1 && VEC == 8 && DEQ_ONLY && !STOCH && !BATCHED, "resident form: 16-bit drop-in threshold mode");
-        extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];          // 32 768 bins
-        __shared__ __attribute__((aligned(16))) uint32_t s_coarse[kCoarseBins];
-        __shared__ uint32_t s_pub[8];
-        __shared__ uint32_t s_cnt[RES * 16 + 16];
-        SelWs* ws = a.selws;
-        const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-        const SegGeom g = seg_geom(a.n_items);
-        const int64_t i0 = (int64_t)blockIdx.x * g.L, i1 = i0 + g.L < a.n_items ? i0 + g.L : a.n_items;
-        const int64_t lastv = a.n_items - 1;
-        STAMP(0, 0);
-        uint32_t epoch0 = 0;
-        if (t == 0) epoch0 = pub_load(&ws->epoch[0]);
-        u4v d[RES];
-#pragma unroll
-        for (int j = 0; j < RES; j++) {
-            // (unconditional, index clamped: a load inside a branch would make the waits below drain the whole queue; the host
-            // picks the smallest RES that covers the segment, so few of these read past it)
-            const int64_t it = i0 + t + (int64_t)j * kSelThreads;
-            d[j] = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(src + (it < lastv ? it : lastv)));
-        }
-        for (int i = t; i < kFineBins / 4; i += kSelThreads) reinterpret_cast<uint4*>(s_hist)[i] = make_uint4(0, 0, 0, 0);
-        for (int i = t; i < 512; i += kSelThreads) s_win[i] = (a.exp_win && i < BFPQ_EXP_WIN_ENTRIES) ? a.exp_win[i] : 0;
-        __syncthreads();
-        {
-            const uint32_t absm = T::ABS | (T::ABS << 16), nanc = (T::INF + 1u) | ((T::INF + 1u) << 16);
-#pragma unroll
-            for (int j = 0; j < RES; j++) {
-                if (i0 + t + (int64_t)j * kSelThreads < i1) {
-                    const uint32_t dd[4] = {d[j].x, d[j].y, d[j].z, d[j].w};
-#pragma unroll
-                    for (int x = 0; x < 4; x++) {
-                        const uint32_t k2 = pk_min_i16_s(dd[x] & absm, nanc);
-                        atomicAdd(&s_hist[k2 & 0xffffu], 1u);
-                        atomicAdd(&s_hist[k2 >> 16], 1u);
-                    }
-                }
-            }
-        }
-        STAMP(0, 1);
-        __syncthreads();
-        STAMP(0, 2);
-        const bool is_last = seg_publish_and_ticket(s_hist, s_coarse, s_pub, ws, res_k, a.n_items * VEC);
-        if (is_last) {
-            STAMP(0, 6);
-            fused_resolve<DT, true>(a.in, a.n_items * VEC, a.n_items, g, res_k, ws, s_hist, true);
-            STAMP(0, 7);
-        }
-        // wait (one lane, bounded) for the epoch to move, then fetch what the resolving workgroup published
-        if (t == 0) {
-            unsigned long long t_start, t_now;
-            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_start) :: "memory");
-            uint32_t ok = 0;
-            for (;;) {
-                if (pub_load(&ws->epoch[0]) != epoch0) { ok = 1; break; }
-                asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_now) :: "memory");
-                if (t_now - t_start > (unsigned long long)res_timeout) break;
-                __builtin_amdgcn_s_sleep(24);                            // (~0.7 us between polls: 255 workgroups read this one line)
-            }
-            s_pub[7] = ok;
-            if (ok) {
-#pragma unroll
-                for (int i = 0; i < 5; i++) s_pub[i] = pub_load(&ws->res_pub[i]);
-            } else atomicOr(&ws->error, 1u);
-        }
-        __syncthreads();
-        if (!s_pub[7]) return;                                   // (gave up: this segment's output is missing, ws->error says so)
-        thr.tau = s_pub[0]; thr.on = s_pub[1] != 0; thr.cut_lo = s_pub[2]; thr.cut_hi = s_pub[3]; thr.within = s_pub[4];
-        thr.teff = 0; thr.ranked = false; thr.before = 0; thr.cut_total = 0; thr.dump = reinterpret_cast<uint4*>(ws->windows);
-        if (!thr.on) thr.tau = 0;
-        const bool cut_seg = thr.on && i0 >= thr.cut_lo && i0 < thr.cut_hi;      // (the cut segment is exactly one segment of this geometry)
-        if (cut_seg) {
-            // ties per (sweep j, wave): tile order inside the segment is j-major, wave-minor
-#pragma unroll
-            for (int j = 0; j < RES; j++) {
-                uint32_t c = 0;
-                if (i0 + t + (int64_t)j * kSelThreads < i1) {
-                    const uint32_t raw[8] = {d[j].x & 0xffffu, d[j].x >> 16, d[j].y & 0xffffu, d[j].y >> 16, d[j].z & 0xffffu, d[j].z >> 16, d[j].w & 0xffffu, d[j].w >> 16};
-                    c = count_eq<DT>(raw, thr.tau);
-                }
-                c = wave_sum(c);
-                if (lane == 0) s_cnt[j * 16 + wv] = c;
-            }
-            __syncthreads();
-            if (wv == 0) {                                           // exclusive scan of the RES * 16 counts, four per lane
-                uint32_t v[4], mine = 0;
-#pragma unroll
-                for (int i = 0; i < 4; i++) { v[i] = 4 * lane + i < RES * 16 ? s_cnt[4 * lane + i] : 0u; mine += v[i]; }
-                uint32_t ex = wave_incl_scan(mine) - mine;
-#pragma unroll
-                for (int i = 0; i < 4; i++) { if (4 * lane + i < RES * 16) s_cnt[4 * lane + i] = ex; ex += v[i]; }
-            }
-            __syncthreads();
-        }
-        STAMP(1, 0);
-        // (spelled out item by item: as a loop the thirteen copies of the item pipeline exceed the unroller's size limit, and a
-        // rolled loop would index d[] at run time, i.e. keep the segment in scratch memory instead of registers)
-        auto step = [&](const int j, const u4v dj) __attribute__((always_inline)) {
-            const int64_t it = i0 + t + (int64_t)j * kSelThreads;
-            if (it - lane < i1) {                                    // (wave-uniform: whole tiles, the last one of the tensor ragged)
-                if (cut_seg) { thr.ranked = true; thr.before = s_cnt[j * 16 + wv]; }
-                body(std::true_type{}, it, u4(dj));
-            }
-        };
-        static_assert(RES == 4 || RES == 8 || RES == 13, "resident form: the item steps below are spelled out for 4, 8 or 13 items per thread");
-        step(0, d[0]); step(1, d[1]); step(2, d[2]); step(3, d[3]);
-        if constexpr (RES > 4) { step(4, d[4]); step(5, d[5]); step(6, d[6]); step(7, d[7]); }
-        if constexpr (RES > 8) { step(8, d[8]); step(9, d[9]); step(10, d[10]); step(11, d[11]); step(12, d[12]); }
-        STAMP(1, 1);
-#ifdef BFPQ_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        STAMP(1, 2);
-#endif
-        return;
-    }
     // Sweep: item = sweep * stride + global thread id.  Loads run two sweeps ahead of the item being
     // processed (index clamped to the last item, never conditional).
     // (the packed-output instantiations are bound by vector-instruction issue, not by memory: they index with 32 bits -- byte
@@ -978,13 +851,6 @@ __global__ void __launch_bounds__(kThreads) k_fused_flat(const FusedArgs a)
     fused_flat_body<DT, NM, SFIRST, STOCH, LPBT, DEQ_ONLY, false, F32IMG, PACK>(a, nullptr);
 }
 
-// the resident form of the unstructured path (see RES in fused_flat_body): one workgroup of 1024 threads per segment
-template <int DT, int LPBT, int RES>
-__global__ void __launch_bounds__(kSelThreads) k_prune_quantize_resident(const FusedArgs a, int64_t k, uint32_t timeout_ticks)
-{
-    fused_flat_body<DT, -1, true, false, LPBT, true, false, false, 0, RES>(a, nullptr, k, timeout_ticks);
-}
-
 // the same item pipeline over a list of tensors (drop-in mode, round-half-even, dense or N:4)
 template <int DT, int NM, bool SFIRST, int LPBT>
 __global__ void __launch_bounds__(kThreads) k_fused_batched(const FusedArgs a, const BatchArgs b)
@@ -1101,32 +967,6 @@ int launch_fused_threshold(const FusedArgs& a, hipStream_t s)
         else hipLaunchKernelGGL((k_fused_flat<DT, -1, true, false, -1, true>), grid, block, 0, s, a);
     } else hipLaunchKernelGGL((k_fused_flat<DT, -1, true, false, -1, false>), grid, block, 0, s, a);
     return (int)hipGetLastError();
-}
-
-template <int DT>
-int launch_resident(const FusedArgs& a, int64_t k, uint32_t timeout_ticks, hipStream_t s)
-{
-    if constexpr (Traits<DT>::VEC == 8) {
-        const SegGeom g = seg_geom(a.n_items);
-        if (g.L > (int64_t)kResItems * kSelThreads || !(a.lpb == 8 || a.lpb == 4)) return BFPQ_E_UNSUPPORTED;
-        const size_t lds = sizeof(uint32_t) * kFineBins;
-        const dim3 grid(g.G), block(kSelThreads);
-#define BFPQ_RES(LP, R) do { \
-            static bool attr_set = false; \
-            if (!attr_set) { \
-                const hipError_t err = hipFuncSetAttribute((const void*)k_prune_quantize_resident<DT, LP, R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-                if (err != hipSuccess) return (int)err; \
-                attr_set = true; \
-            } \
-            hipLaunchKernelGGL((k_prune_quantize_resident<DT, LP, R>), grid, block, lds, s, a, k, timeout_ticks); \
-        } while (0)
-        // items per thread: the smallest instantiation that holds the segment
-        if (g.L <= 4 * kSelThreads) { if (a.lpb == 8) BFPQ_RES(8, 4); else BFPQ_RES(4, 4); }
-        else if (g.L <= 8 * kSelThreads) { if (a.lpb == 8) BFPQ_RES(8, 8); else BFPQ_RES(4, 8); }
-        else { if (a.lpb == 8) BFPQ_RES(8, kResItems); else BFPQ_RES(4, kResItems); }
-#undef BFPQ_RES
-        return (int)hipGetLastError();
-    } else return BFPQ_E_UNSUPPORTED;
 }
 
 // N:8 (16-bit dtypes): few instantiations -- lane groups 8 (block 64) or run-time

@@ -15,7 +15,6 @@ namespace bfpq_dev {
 
 int BFPQ_CAT(fused_launch_, BFPQ_FUSED_DT)(const FusedArgs& a, int M, bool sfirst, hipStream_t s) { return launch_fused<BFPQ_FUSED_DT>(a, M, sfirst, s); }
 int BFPQ_CAT(fused_threshold_, BFPQ_FUSED_DT)(const FusedArgs& a, hipStream_t s) { return launch_fused_threshold<BFPQ_FUSED_DT>(a, s); }
-int BFPQ_CAT(fused_resident_, BFPQ_FUSED_DT)(const FusedArgs& a, int64_t k, uint32_t timeout_ticks, hipStream_t s) { return launch_resident<BFPQ_FUSED_DT>(a, k, timeout_ticks, s); }
 int BFPQ_CAT(fused_mx8_, BFPQ_FUSED_DT)(const FusedArgs& a, hipStream_t s) { return launch_fused_mx8<BFPQ_FUSED_DT>(a, s); }
 int BFPQ_CAT(fused_batched_, BFPQ_FUSED_DT)(const FusedArgs& a, const BatchArgs& b, int M, bool sfirst, hipStream_t s)
 {
@@ -23,7 +22,3 @@ int BFPQ_CAT(fused_batched_, BFPQ_FUSED_DT)(const FusedArgs& a, const BatchArgs&
 }
 
 }  // namespace bfpq_dev
-
-#if defined(BFPQ_STAMPS) && BFPQ_FUSED_DT == 2
-extern "C" int bfpq_debug_stamps_fused(void* host_dst) { return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(bfpq_dev::bfpq_g_stamps), sizeof(bfpq_dev::bfpq_g_stamps)); }
-#endif

@@ -31,8 +31,7 @@ extern "C" __attribute__((visibility("hidden"))) int bfpq_g_mx8_variant;   // bf
 #include "bfpq_quant_math.h"
 
 extern "C" { __attribute__((visibility("hidden"))) int bfpq_g_max_grid = BFPQ_MAXGRID; }
-static int g_resident = 0;            // (measured: 48-49 us against 45.7 us for the two launches on [5120,5120] bf16, see DESIGN.md 5b -- opt-in)
-static int g_resident_timeout_us = 200000;
+
 
 using namespace bfpq_dev;
 
@@ -550,8 +549,6 @@ int bfpq_tune(int key, int value)
     if (key == BFPQ_TUNE_MAX_GRID && value >= 1 && value <= 65535) { bfpq_g_max_grid = value; return 0; }
     if (key == BFPQ_TUNE_GEMM_ROW_TILES && (value == 0 || value == 1 || value == 2 || value == 4)) { bfpq_g_gemm_rt = value; return 0; }
     if (key == BFPQ_TUNE_MX8_VARIANT && value >= -1 && value <= 6) { bfpq_g_mx8_variant = value; return 0; }
-    if (key == BFPQ_TUNE_RESIDENT && (value == 0 || value == 1)) { g_resident = value; return 0; }
-    if (key == BFPQ_TUNE_RESIDENT_TIMEOUT_US && value >= 0 && value <= 20000000) { g_resident_timeout_us = value; return 0; }
     return BFPQ_E_ARG;
 }
 
@@ -846,31 +843,6 @@ int bfpq_quantize_threshold(const void* in, void* out_deq, void* out_codes, int8
     return launch_quant_rows(tmp, out_deq, out_codes, out_exp, rows, cols, dtype, block_size, mant_bits, eps_dt, code_bits, stoch_seed, exp_win, s);
 }
 
-// compute units of the current device (cached per ordinal)
-static int device_cus()
-{
-    static int cus[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    if (!cus[dev]) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        cus[dev] = n;
-    }
-    return cus[dev];
-}
-
-int bfpq_prune_quantize_is_resident(const void* in, void* out, int64_t rows, int64_t cols, int dtype, int block_size)
-{
-    if (!g_resident || dtype == BFPQ_F32 || dtype < 0 || dtype > 2 || block_size <= 0 || rows * cols <= 0) return 0;
-    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) != 0) return 0;
-    if (!fused_shape_ok(rows, cols, dtype, block_size, 0, 0)) return 0;
-    const int lpb = block_size / dtype_vec(dtype);
-    if (!(lpb == 8 || lpb == 4)) return 0;
-    const SegGeom g = seg_geom(rows * cols / dtype_vec(dtype));
-    return g.L <= (int64_t)kResItems * kSelThreads && g.G <= device_cus();
-}
-
 int bfpq_prune_quantize(const void* in, void* out, int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits,
                         double epsilon, int64_t k, const uint8_t* exp_win, void* ws, void* stream)
 {
@@ -878,19 +850,6 @@ int bfpq_prune_quantize(const void* in, void* out, int64_t rows, int64_t cols, i
     if (rows * cols == 0) return 0;
     if (!in || !out || !ws || !exp_win || in == out || mant_bits < 0 || mant_bits > 23) return BFPQ_E_ARG;
     if (rows * cols >= ((int64_t)1 << 32)) return BFPQ_E_UNSUPPORTED;
-    if (bfpq_prune_quantize_is_resident(in, out, rows, cols, dtype, block_size)) {
-        const float eps_dt = h_round((float)epsilon, dtype);
-        FusedArgs a;
-        a.in = in; a.out_deq = out; a.out_codes = nullptr; a.out_exp = nullptr;
-        a.n_items = rows * cols / dtype_vec(dtype);
-        a.exp_win = exp_win; a.nm_lut = nullptr; a.seed = 0; a.eps_dt = eps_dt;
-        a.lpb = block_size / dtype_vec(dtype);
-        a.mant_bits = mant_bits; a.N = 0; a.code_bits = 0;
-        a.force_slow = mant_bits > (dtype == BFPQ_F16 ? 11 : 8);
-        set_hot16(a, dtype, mant_bits, eps_dt);
-        a.selws = (SelWs*)ws;
-        return fused_resident(dtype, a, k, (uint32_t)g_resident_timeout_us * 100u, (hipStream_t)stream);
-    }
     const int rc = bfpq_select(in, rows * cols, dtype, k, ws, stream);
     if (rc) return rc;
     return bfpq_quantize_threshold(in, out, nullptr, nullptr, rows, cols, dtype, block_size, mant_bits, epsilon, 0, 0, exp_win, ws, nullptr, stream);
@@ -928,12 +887,6 @@ int bfpq_prune_quantize_batched(const bfpq_prune_desc* descs, int n, int dtype, 
         if (!d.in_dev || !d.out_dev || d.in_dev == d.out_dev) { rc = BFPQ_E_ARG; break; }
         const int w = i % W;
         if (app_recorded[w] && !hipok(hipStreamWaitEvent(sm, app_done[w], 0))) break;        // the workspace's previous tensor has been applied
-        if (bfpq_prune_quantize_is_resident(d.in_dev, d.out_dev, d.rows, d.cols, dtype, block_size)) {
-            // (one launch does it all; it stays on the main stream and overlaps the other stream's apply launch all the same)
-            rc = bfpq_prune_quantize(d.in_dev, d.out_dev, d.rows, d.cols, dtype, block_size, mant_bits, epsilon, d.k, exp_win, wss[w], stream);
-            app_recorded[w] = false;
-            continue;
-        }
         rc = bfpq_select(d.in_dev, d.rows * d.cols, dtype, d.k, wss[w], stream);
         if (rc) break;
         if (!hipok(hipEventRecord(sel_done[w], sm)) || !hipok(hipStreamWaitEvent(sa, sel_done[w], 0))) break;
@@ -953,17 +906,6 @@ int bfpq_prune_quantize_batched(const bfpq_prune_desc* descs, int n, int dtype, 
     if (fork) (void)hipEventDestroy(fork);
     for (int w = 0; w < W; w++) { if (sel_done[w]) (void)hipEventDestroy(sel_done[w]); if (app_done[w]) (void)hipEventDestroy(app_done[w]); }
     return rc;
-}
-
-int bfpq_select_error(void* ws, void* stream)
-{
-    if (!ws) return BFPQ_E_ARG;
-    uint32_t e = 0;
-    SelWs* w = (SelWs*)ws;
-    if (hipMemcpyAsync(&e, &w->error, 4, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return BFPQ_E_ARG;
-    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return BFPQ_E_ARG;
-    if (e) (void)hipMemsetAsync(&w->error, 0, 4, (hipStream_t)stream);
-    return e ? 1 : 0;
 }
 
 }  // extern "C"

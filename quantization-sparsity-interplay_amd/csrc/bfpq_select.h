@@ -1,6 +1,5 @@
 // bfpq_select.h -- device code shared by the launches that select the global magnitude threshold (bfpq_unstructured.hip: the
-// histogram launch; bfpq_fused.h: the resident prune + quantize kernel): publishing a segment's counts, the ticket, and the
-// resolve step that the last workgroup runs.  Reference: src/transformers/bfp/bfp_ops.py:61-71.
+// histogram launch): publishing a segment's counts, the ticket, and the resolve step that the last workgroup runs.  Reference: src/transformers/bfp/bfp_ops.py:61-71.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "bfpq.h"
@@ -107,7 +106,7 @@ __device__ __forceinline__ uint32_t pick_lane(bool cond, uint32_t v)
 }
 
 template <int DT, bool FAST>
-__device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int64_t n_items, const SegGeom g, int64_t k, SelWs* ws, uint32_t* lds, bool publish)
+__device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int64_t n_items, const SegGeom g, int64_t k, SelWs* ws, uint32_t* lds)
 {
     constexpr int VEC = Traits<DT>::VEC;
     constexpr int NC = BFPQ_SELECT_HIST_COPIES;
@@ -258,14 +257,6 @@ __device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int
             st->flags = 1u; st->cut_lo = lo; st->cut_hi = hi; st->cut_within = within; st->cut_total = ctot;
             st->reserved = 0;
             ws->ticket = 0u;                                     // ready for the next call
-            if (publish) {
-                // the resident kernel's other workgroups are waiting for exactly these words: write-through stores, drained, then
-                // the epoch they poll
-                pub_store(&ws->res_pub[0], tau); pub_store(&ws->res_pub[1], k > 0 ? 1u : 0u);
-                pub_store(&ws->res_pub[2], lo); pub_store(&ws->res_pub[3], hi); pub_store(&ws->res_pub[4], within);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_fetch_add(&ws->epoch[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
         }
     }
 }

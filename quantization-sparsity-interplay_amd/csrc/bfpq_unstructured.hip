@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
     if (fuse) {                                             // (host: only with nbits == 15, first and last pass in one)
         if (!seg_publish_and_ticket(s_hist, s_coarse, s_res, ws, k, numel_global)) return;
         STAMP(0, 6);
-        fused_resolve<DT, FAST>(in, numel, n_items, g, k, ws, s_hist, false);
+        fused_resolve<DT, FAST>(in, numel, n_items, g, k, ws, s_hist);
         STAMP(0, 7);
         return;
     }

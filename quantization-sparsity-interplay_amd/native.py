@@ -83,9 +83,7 @@ def load_library():
         L.bfpq_select_ws_bytes.restype = i64
         L.bfpq_select.argtypes = [vp, i64, i32, i64, vp, vp]
         L.bfpq_prune_quantize.argtypes = [vp, vp, i64, i64, i32, i32, i32, dbl, i64, vp, vp, vp]
-        L.bfpq_prune_quantize_is_resident.argtypes = [vp, vp, i64, i64, i32, i32]
         L.bfpq_prune_quantize_batched.argtypes = [vp, i32, i32, i32, i32, dbl, vp, vp, i32, vp, vp]
-        L.bfpq_select_error.argtypes = [vp, vp]
         L.bfpq_select_hist.argtypes = [vp, i64, i32, i32, i64, i64, vp, vp, vp]
         L.bfpq_select_resolve.argtypes = [vp, i64, i32, i32, i64, vp, i32, i32, vp, vp, vp]
         L.bfpq_threshold_apply.argtypes = [vp, vp, i64, i32, vp, vp]
@@ -107,7 +105,7 @@ def load_library():
         L.bfpq_hbfp_linear_mx8_splitk.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, i64, i32, vp]
         for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_is_fused", "bfpq_nm_sparsify",
                      "bfpq_select_passes", "bfpq_select", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
-                     "bfpq_prune_quantize", "bfpq_prune_quantize_is_resident", "bfpq_prune_quantize_batched", "bfpq_select_error",
+                     "bfpq_prune_quantize", "bfpq_prune_quantize_batched",
                      "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize", "bfpq_hbfp_linear_slices",
                      "bfpq_hbfp_linear_decode", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled",
                      "bfpq_mx8_from_hbfp", "bfpq_quantize_mx8", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8",
@@ -120,7 +118,7 @@ def load_library():
 EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_mx8_parts", "bfpq_hbfp_linear_mx8_splitk", "bfpq_quantize_mx8", "bfpq_mx8_from_hbfp", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_select_ws_bytes", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_is_fused", "bfpq_nm_sparsify",
                     "bfpq_select_passes", "bfpq_select", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
-                    "bfpq_prune_quantize", "bfpq_prune_quantize_is_resident", "bfpq_prune_quantize_batched", "bfpq_select_error",
+                    "bfpq_prune_quantize", "bfpq_prune_quantize_batched",
                     "bfpq_threshold_apply", "bfpq_quantize_threshold")
 
 
@@ -520,9 +518,8 @@ def quantize_threshold(t, ws, block_size, mant_bits, epsilon, want_deq=True, cod
 
 
 def prune_quantize(t, k, ws, block_size, mant_bits, epsilon, out=None):
-    """the whole s-first unstructured drop-in op on one device, out = Q(S_k(t)) (bfpq_prune_quantize): the resident kernel --
-    ONE launch, the tensor read once -- where it applies (16-bit dtype, block 32 / 64, up to 54.5 MB), else the selection
-    launch + the fused prune + quantize launch.  Round-half-even."""
+    """the whole s-first unstructured drop-in op on one device, out = Q(S_k(t)) (bfpq_prune_quantize): the selection launch +
+    the fused prune + quantize launch behind one call.  Round-half-even."""
     require_device_tensor(t)
     L = load_library()
     src = t.contiguous()
@@ -635,13 +632,6 @@ class PruneQuantizeList:
             else:
                 self._issue(pipelined)
         return self.outputs
-
-
-def select_error(ws):
-    """True if a resident launch on this workspace gave up waiting for the resolved threshold (its output is then incomplete);
-    synchronises the current stream, clears the word"""
-    with torch.cuda.device(ws.device):
-        return bool(load_library().bfpq_select_error(_ptr(ws.ws), ctypes.c_void_p(torch.cuda.current_stream(ws.device).cuda_stream)))
 
 
 def threshold_apply(t, ws, out=None):

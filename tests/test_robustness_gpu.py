@@ -163,95 +163,6 @@ def test_select_workspace_and_graph_capture():
     assert (x.device.index, side.cuda_stream) in bfp_ops._select_ws
 
 
-def _tune(key, value):
-    assert native.load_library().bfpq_tune(key, value) == 0
-
-
-@pytest.mark.parametrize("dname", ["bf16", "f16"])
-def test_resident_kernel_equals_two_launches(dname):
-    """bfpq_prune_quantize: the resident one-read kernel (segment in registers, last workgroup resolves, the others wait --
-    bounded -- for the threshold) against the two-launch path, bit for bit: real-valued and tie-heavy inputs, every kind of cut
-    (no tie pruned / all / a cut inside a segment), shapes with a ragged last segment and a ragged last tile, block 32 and 64,
-    k = 0 and k = numel, graph replay."""
-    dt = torch.bfloat16 if dname == "bf16" else torch.float16
-    L = native.load_library()
-    shapes = [(512, 1024), (2048, 4096), (1000, 192), (64, 64), (5120, 5120), (3, 64), (4097, 576)]
-    try:
-        _tune(3, 1)
-        for si, (rows, cols) in enumerate(shapes):
-            real = synth(rows, cols, dt, 0.02, seed=50 + si)
-            coarse = (synth(rows, cols, dt, 1.0, seed=90 + si).float() * 2).round().div(2).to(dt)      # ~9 distinct magnitudes: huge tie classes
-            for xc, tag in ((real, "real"), (coarse, "coarse")):
-                x = xc.to(DEV)
-                out = torch.empty_like(x)
-                for blk, m in ((64, 3), (32, 7)):
-                    assert L.bfpq_prune_quantize_is_resident(x.data_ptr(), out.data_ptr(), rows, cols, native.DTYPE_CODE[dt], blk) == 1, (rows, cols)
-                    for frac in (0.5, 0.31, 0.9):
-                        c = cfg(mant_bits=m, block_size=blk, w_sparsity=True, sparsity_mode='unstructured', sparsity_frac=frac)
-                        _tune(3, 0)
-                        two = bfp_ops.float_to_bfp_blocked(x, **c, identifier='w')
-                        _tune(3, 1)
-                        res = bfp_ops.float_to_bfp_blocked(x, **c, identifier='w')
-                        assert torch.equal(res.view(torch.int16), two.view(torch.int16)), (tag, rows, cols, blk, frac)
-                ws = bfp_ops._workspace(x.device)
-                for k in (0, x.numel(), 1, x.numel() - 1):
-                    _tune(3, 0)
-                    two = native.prune_quantize(x, k, ws, 64, 3, 1e-8)
-                    _tune(3, 1)
-                    res = native.prune_quantize(x, k, ws, 64, 3, 1e-8)
-                    assert torch.equal(res.view(torch.int16), two.view(torch.int16)), (tag, rows, cols, "k", k)
-                assert not native.select_error(ws)
-        # too large for the registers (or fp32): the same entry point takes the two launches
-        big = torch.empty(4096, 11008, dtype=dt, device=DEV)
-        assert L.bfpq_prune_quantize_is_resident(big.data_ptr(), big.data_ptr(), 4096, 11008, native.DTYPE_CODE[dt], 64) == 0
-        assert L.bfpq_prune_quantize_is_resident(big.data_ptr(), big.data_ptr(), 64, 64, native.F32, 64) == 0
-        # hipGraph: capture three calls, replay twice
-        xs = [synth(1024, 2048, dt, seed=s).to(DEV) for s in (1, 2, 3)]
-        c = cfg(w_sparsity=True, sparsity_mode='unstructured')
-        _tune(3, 0)
-        want = [bfp_ops.float_to_bfp_blocked(x, **c, identifier='w').clone() for x in xs]
-        _tune(3, 1)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                outs = [bfp_ops.float_to_bfp_blocked(x, **c, identifier='w') for x in xs]
-            for _ in range(2):
-                graph.replay()
-            side.synchronize()
-            for o, w in zip(outs, want):
-                assert torch.equal(o, w)
-            assert not native.select_error(bfp_ops._workspace(xs[0].device))
-        torch.cuda.current_stream().wait_stream(side)
-    finally:
-        _tune(3, 0)
-
-
-def test_resident_kernel_gives_up_loudly():
-    """a workgroup whose wait for the resolved threshold runs out stores nothing and raises the workspace's error word: forced
-    here with a zero time limit (every workgroup but the resolving one gives up at once).  Nothing hangs; the error is
-    reported; the next call with the normal limit is right again."""
-    x = synth(2048, 4096, torch.bfloat16).to(DEV)
-    c = cfg(w_sparsity=True, sparsity_mode='unstructured')
-    try:
-        _tune(3, 0)
-        want = bfp_ops.float_to_bfp_blocked(x, **c, identifier='w')
-        _tune(3, 1)
-        ws = bfp_ops._workspace(x.device)
-        assert not native.select_error(ws)
-        _tune(4, 0)
-        bfp_ops.float_to_bfp_blocked(x, **c, identifier='w')
-        assert native.select_error(ws), "the give-up was not reported"
-        assert not native.select_error(ws)                               # (reading clears the word)
-        _tune(4, 200000)
-        got = bfp_ops.float_to_bfp_blocked(x, **c, identifier='w')
-        assert torch.equal(got, want) and not native.select_error(ws)
-    finally:
-        _tune(3, 0)
-        _tune(4, 200000)
-
-
 @pytest.mark.parametrize("dname", ["bf16", "f32"])
 def test_unstructured_list_pipelined_over_two_streams(dname):
     """float_to_bfp_blocked_many / PreparedMany with unstructured pruning (BASELINE config 4's "all Linear weights"): the

@@ -17,19 +17,12 @@ xs = [(torch.randn(rows, cols, generator=torch.Generator().manual_seed(1 + i)) *
 x = xs[0]
 L = native.load_library()
 ws = bfp_ops._workspace(x.device)
-resident = os.environ.get("RESIDENT", "0") == "1"
-if resident:
-    assert L.bfpq_tune(3, 1) == 0
-outs = [torch.empty_like(x) for x in xs]
 for i in range(3 * len(xs) + 1):                  # (rotating inputs and outputs: neither L2 nor the Infinity Cache serves the stream)
     x = xs[i % len(xs)]
-    if resident:
-        native.prune_quantize(x, x.numel() // 2, ws, 64, 3, 1e-8, out=outs[i % len(xs)])
-    else:
-        native.select_threshold(x, x.numel() // 2, ws)
+    native.select_threshold(x, x.numel() // 2, ws)
 torch.cuda.synchronize()
 buf = np.zeros((3, 512, 8), dtype=np.uint64)
-assert (L.bfpq_debug_stamps_fused if resident else L.bfpq_debug_stamps)(ctypes.c_void_p(buf.ctypes.data)) == 0
+assert L.bfpq_debug_stamps(ctypes.c_void_p(buf.ctypes.data)) == 0
 s = buf[0][:256, :8].astype(np.int64)
 s = s[s[:, 0] > 0]
 t0 = s[:, 0].min()
@@ -47,8 +40,3 @@ if len(last):
     if len(r2):
         rr = (r2[-1] - t0) * 0.01
         print("  resolve step: entry %.2f | coarse bin known %.2f | slice offsets %.2f | slices in %.2f | tau %.2f | cut %.2f us" % tuple(rr))
-if resident:
-    a = buf[1][:256, :3].astype(np.int64)
-    a = a[a[:, 0] > 0]
-    ra = (a - t0) * 0.01
-    print(f"  resident apply: start min {ra[:, 0].min():.2f} median {np.median(ra[:, 0]):.2f} max {ra[:, 0].max():.2f} | stores issued min {ra[:, 1].min():.2f} median {np.median(ra[:, 1]):.2f} max {ra[:, 1].max():.2f} | stores done min {ra[:, 2].min():.2f} median {np.median(ra[:, 2]):.2f} max {ra[:, 2].max():.2f} us")
