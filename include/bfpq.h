@@ -134,7 +134,8 @@ int bfpq_nm_sparsify(const void* in_dev, void* out_dev, int64_t rows, int64_t co
  * Single device, TWO launches for a 16-bit dtype:
  *   1. bfpq_select(...)            one launch: per-segment histograms, and the LAST workgroup to finish (an atomic ticket, no
  *                                  workgroup ever waits for another) resolves threshold + tie bookkeeping into ws_dev.
- *                                  fp32: three histogram/resolve launch pairs (11 + 11 + 9 bits).
+ *                                  fp32: two such launches (the high 15 bits of the key, then the low 16 bits of the keys that
+ *                                  share them): the tensor is read three times in all, the launch-pair form reads it four times.
  *   2. bfpq_threshold_apply(...) or bfpq_quantize_threshold(...)   prune (and quantize) in one pass
  * ws_dev must be ZERO before its first use; every call leaves it ready for the next one.
  *
@@ -149,7 +150,7 @@ int bfpq_nm_sparsify(const void* in_dev, void* out_dev, int64_t rows, int64_t co
  *                                and the tie bookkeeping of this device's slab in ws_dev; clears the local histogram for its
  *                                next use (zero_hist_dev = hist_dev)
  *   then the apply launch as above.  (hist_dev = NULL / hist_all_dev = NULL run the same launches on histogram buffers inside
- *   ws_dev: what bfpq_select issues for fp32.)
+ *   ws_dev; fp32 takes three pairs, 11 + 11 + 9 bits.)
  * ws_dev: BFPQ_SELECT_WS_BYTES bytes, zeroed once, 16-byte aligned; it begins with a bfpq_select_state.
  * k is the GLOBAL prune count int(numel_global * frac) (bfp_ops.py:66); numel_global < 2^32.
  * in_dev and out_dev of the apply launch must not alias (the tie ranks are counted from the input while other tiles are written).
@@ -161,12 +162,12 @@ int bfpq_nm_sparsify(const void* in_dev, void* out_dev, int64_t rows, int64_t co
 #define BFPQ_SELECT_WINDOW_BINS 2048
 #define BFPQ_SELECT_HIST_ENTRIES (32768 + 256)   /* fine bins, then (16-bit dtypes) 256 coarse bins of 128 */
 #define BFPQ_SELECT_HIST_COPIES 8                /* a device accumulates into 8 copies (cuts the contention of the flush) */
-#define BFPQ_SELECT_WS_BYTES (BFPQ_SELECT_STATE_BYTES + 4 * (12 + BFPQ_SELECT_HIST_COPIES * 256 + 3 * BFPQ_SELECT_HIST_COPIES * BFPQ_SELECT_HIST_ENTRIES + \
-                              2 * BFPQ_SELECT_MAX_SEGMENTS + BFPQ_SELECT_MAX_SEGMENTS * BFPQ_SELECT_WINDOW_BINS))
+#define BFPQ_SELECT_WS_BYTES (BFPQ_SELECT_STATE_BYTES + 4 * (12 + BFPQ_SELECT_HIST_COPIES * 512 + 3 * BFPQ_SELECT_HIST_COPIES * BFPQ_SELECT_HIST_ENTRIES + \
+                              2 * BFPQ_SELECT_MAX_SEGMENTS + 2 * BFPQ_SELECT_MAX_SEGMENTS * BFPQ_SELECT_WINDOW_BINS))
 
 int bfpq_select_passes(int dtype);
 int64_t bfpq_select_ws_bytes(void);
-/* single device: every launch of the selection (16-bit dtypes: ONE) */
+/* single device: every launch of the selection (16-bit dtypes: ONE, fp32: TWO) */
 int bfpq_select(const void* in_dev, int64_t numel, int dtype, int64_t k, void* ws_dev, void* stream);
 int bfpq_select_hist(const void* in_dev, int64_t numel, int dtype, int pass, int64_t k, int64_t numel_global,
                      void* ws_dev, uint32_t* hist_dev, void* stream);

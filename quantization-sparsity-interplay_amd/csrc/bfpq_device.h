@@ -218,13 +218,15 @@ struct SelWs {
     bfpq_select_state st;
     uint32_t ticket;                          // fused histogram + resolve launch: workgroups that have published their segment
     uint32_t pad_[11];
-    uint32_t coarse[BFPQ_SELECT_HIST_COPIES][kCoarseBins];   // fused launch: coarse histogram (256 bins of 128), zero between calls
+    uint32_t coarse[BFPQ_SELECT_HIST_COPIES][2 * kCoarseBins];   // fused launch: coarse histogram (256 bins of 128; fp32's low-16 digit: 512), zero between calls
     // histogram buffers of the launch-pair path (fp32; diagnostics), one per radix pass; all zero between calls: the APPLY launch
     // clears what the histogram launches of its call dirtied (see thr_setup; bfpq_select_reset after a select with no apply)
     uint32_t hist[3][BFPQ_SELECT_HIST_COPIES][BFPQ_SELECT_HIST_ENTRIES];
     uint32_t seg_ties[kMaxSeg];               // elements equal to tau per segment (resolve launch, window-miss path)
     uint32_t seg_win[kMaxSeg];                // first bin of the segment's window | bit 31: magnitudes outside the window exist | bit 30: 128-bin window
     uint32_t windows[kMaxSeg][kWinBins];      // (the apply launch also dumps the ordinary workgroups' cut-segment tiles here)
+    uint32_t windows2[kMaxSeg][kWinBins];     // fp32's low-16 digit: a second window per segment at a position every workgroup derives from the
+                                              // state alone (where the threshold lies if the low bits are spread evenly); directly behind `windows`
 };
 static_assert(sizeof(SelWs) == BFPQ_SELECT_WS_BYTES, "bfpq.h: BFPQ_SELECT_WS_BYTES");
 static_assert(offsetof(SelWs, hist) % 16 == 0 && offsetof(SelWs, windows) % 16 == 0 && offsetof(SelWs, coarse) % 16 == 0, "SelWs: 16-byte aligned arrays");

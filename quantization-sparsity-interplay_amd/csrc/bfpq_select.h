@@ -23,61 +23,91 @@ static __device__ unsigned long long bfpq_g_stamps[3][512][8];        // (one co
 __device__ __forceinline__ void pub_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t pub_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// After the streaming loop and a barrier (the LDS histogram of the segment is complete; 15-bit keys, 1024 threads): publish the
-// segment -- its 256 coarse sums into one of the workspace's coarse-histogram copies, a 2048-bin window of the fine histogram
-// around the segment's own k-quantile, and the window's position -- then draw the ticket.  True for the LAST workgroup of
-// the grid: everything every segment published is in memory when it returns.  s_coarse: 256 words, 16-byte aligned;
-// s_res: 4 words.  Nobody waits for anybody here.
-__device__ __forceinline__ bool seg_publish_and_ticket(const uint32_t* s_hist, uint32_t* s_coarse, uint32_t* s_res, SelWs* ws,
-                                                       int64_t k, int64_t numel_global)
+// value of `v` in the lowest lane whose `cond` holds (0 when none does), for every lane
+__device__ __forceinline__ uint32_t pick_lane(bool cond, uint32_t v)
+{
+    const unsigned long long m = __ballot(cond);
+    if (!m) return 0u;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)__ffsll((long long)m) - 1));
+}
+
+// fine bin b of the segment's LDS histogram: 32-bit counters, or (U16) two 16-bit counters per word (bin 2i low half, 2i + 1 high)
+template <bool U16> __device__ __forceinline__ uint32_t lds_bin(const uint32_t* s_hist, uint32_t b)
+{
+    if constexpr (U16) { const uint32_t w = s_hist[b >> 1]; return (b & 1u) ? w >> 16 : w & 0xffffu; }
+    else return s_hist[b];
+}
+
+// coarse sums (NCB coarse bins of 128 fine bins) of the finished LDS histogram -> s_coarse; every thread sums 32 words with
+// 16-byte LDS reads in a rotated order, then a reduction over the 1024 / NCB threads of a coarse bin.  1024 threads.
+template <int NCB, bool U16>
+__device__ __forceinline__ void coarse_from_lds(const uint32_t* s_hist, uint32_t* s_coarse)
+{
+    constexpr int TPC = kSelThreads / NCB;                    // threads per coarse bin: 4 (256 bins of 128 words) or 2 (512 bins of 64 words)
+    constexpr int WPC = U16 ? 64 : 128;                       // words per coarse bin
+    static_assert(TPC * 32 == WPC, "coarse_from_lds: 32 words per thread");
+    const int t = threadIdx.x, q = t / TPC, r = t % TPC;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint4 c4 = *reinterpret_cast<const uint4*>(&s_hist[q * WPC + ((j + q) & 7) * (TPC * 4) + r * 4]);
+        if constexpr (U16) sum += (c4.x & 0xffffu) + (c4.x >> 16) + (c4.y & 0xffffu) + (c4.y >> 16) + (c4.z & 0xffffu) + (c4.z >> 16) + (c4.w & 0xffffu) + (c4.w >> 16);
+        else sum += c4.x + c4.y + c4.z + c4.w;
+    }
+    sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1, 0xf, 0xf, false);          // quad_perm [1,0,3,2]
+    if constexpr (TPC == 4) sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+    if (r == 0) s_coarse[q] = sum;
+}
+
+// After the streaming loop, a barrier and the coarse sums (s_coarse[NCB], 16-byte aligned, complete): publish the segment -- its
+// coarse sums into one of the workspace's coarse-histogram copies, a 2048-bin window of the fine histogram around the segment's
+// own quantile (target_frac of its elements), and the window's position -- then draw the ticket.  True for the LAST workgroup
+// of the grid: everything every segment published is in memory when it returns.  fine(b): the segment's count of fine bin b.
+// clo2 >= 0: also a second window at coarse bin clo2 (a position all workgroups share).  s_res: 4 words.  1024 threads; nobody
+// waits for anybody here.
+template <int NCB, class F>
+__device__ __forceinline__ bool seg_publish_and_ticket(const uint32_t* s_coarse, uint32_t* s_res, SelWs* ws, double target_frac, F&& fine, int clo2 = -1)
 {
     const int t = threadIdx.x;
     const int copy = blockIdx.x % BFPQ_SELECT_HIST_COPIES;
-    {
-        // coarse histogram (256 bins of 128): four threads per coarse bin, each sums 32 bins with 16-byte LDS reads in a
-        // rotated order (two lanes per bank), then a quad reduction
-        const int q = t >> 2, r = t & 3;
-        uint32_t sum = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint4 c4 = *reinterpret_cast<const uint4*>(&s_hist[q * 128 + ((j + q) & 7) * 16 + r * 4]);
-            sum += c4.x + c4.y + c4.z + c4.w;
-        }
-        sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
-        sum += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sum, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
-        if (r == 0) { s_coarse[q] = sum; if (sum) atomicAdd(&ws->coarse[copy][q], sum); }
-    }
-    __syncthreads();
+    if (t < NCB) { const uint32_t c = s_coarse[t]; if (c) atomicAdd(&ws->coarse[copy][t], c); }
     STAMP(0, 3);
-    // window: the 16 coarse bins (2048 bins) around the one that holds the segment's own k-quantile (first wave: four coarse
+    // window: the 16 coarse bins (2048 bins) around the one that holds the segment's own quantile (first wave: NCB / 64 coarse
     // sums per lane, one wave scan)
     if (t < 64) {
-        const uint4 c4 = *reinterpret_cast<const uint4*>(&s_coarse[t * 4]);
-        const uint32_t mine = c4.x + c4.y + c4.z + c4.w;
+        constexpr int PER = NCB / 64;
+        uint32_t c[PER], mine = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { c[j] = s_coarse[t * PER + j]; mine += c[j]; }
         const uint32_t incl = wave_incl_scan(mine);
         const uint32_t seg_elems = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        uint64_t target = numel_global > 0 ? (uint64_t)((double)seg_elems * ((double)k / (double)numel_global)) : 0ull;   // (an anchor, not a count)
+        uint64_t target = (uint64_t)((double)seg_elems * target_frac);                          // (an anchor, not a count)
         if (seg_elems && target >= seg_elems) target = seg_elems - 1;
         const uint32_t excl = incl - mine;
-        if (t == 0) s_res[0] = 0;
-        if (mine && excl <= target && target < (uint64_t)excl + mine) {
-            uint32_t e = excl;
-            int A = t * 4;
-            if (target >= e + c4.x) { e += c4.x; A++; if (target >= e + c4.y) { e += c4.y; A++; if (target >= e + c4.z) A++; } }
-            int clo = A - kWinBins / 256;
-            clo = clo < 0 ? 0 : (clo > kCoarseBins - kWinBins / 128 ? kCoarseBins - kWinBins / 128 : clo);
-            uint32_t inside = 0;
-            for (int j = 0; j < kWinBins / 128; j++) inside += s_coarse[clo + j];
-            s_res[0] = (uint32_t)clo * 128u;
-            pub_store(&ws->seg_win[blockIdx.x], ((uint32_t)clo * 128u) | (inside != seg_elems ? 0x80000000u : 0u));
+        const bool hit = mine && excl <= target && target < (uint64_t)excl + mine;
+        uint32_t e = excl;
+        int A = t * PER;
+#pragma unroll
+        for (int j = 0; j < PER - 1; j++) { if (target >= (uint64_t)e + c[j]) { e += c[j]; A = t * PER + j + 1; } else break; }
+        const int Aq = (int)pick_lane(hit, (uint32_t)A);
+        int clo = Aq - kWinBins / 256;
+        clo = clo < 0 ? 0 : (clo > NCB - kWinBins / 128 ? NCB - kWinBins / 128 : clo);
+        uint32_t inside = t < kWinBins / 128 ? s_coarse[clo + t] : 0u;
+        inside = wave_sum(inside);
+        if (t == 0) {
+            s_res[0] = seg_elems ? (uint32_t)clo * 128u : 0u;
+            pub_store(&ws->seg_win[blockIdx.x], seg_elems ? (((uint32_t)clo * 128u) | (inside != seg_elems ? 0x80000000u : 0u)) : 0u);   // (empty segment: no window, nothing outside it)
         }
-        if (seg_elems == 0 && t == 0) pub_store(&ws->seg_win[blockIdx.x], 0u);          // (an empty segment: no window, nothing outside it)
     }
     __syncthreads();
     STAMP(0, 4);
-    const int lo = (int)s_res[0];
-    pub_store(&ws->windows[blockIdx.x][t], s_hist[lo + t]);
-    pub_store(&ws->windows[blockIdx.x][kSelThreads + t], s_hist[lo + kSelThreads + t]);
+    const uint32_t lo = s_res[0];
+    pub_store(&ws->windows[blockIdx.x][t], fine(lo + (uint32_t)t));
+    pub_store(&ws->windows[blockIdx.x][kSelThreads + t], fine(lo + (uint32_t)(kSelThreads + t)));
+    if (clo2 >= 0) {                                         // the second window (same for every segment: coarse bins clo2 .. clo2 + 15)
+        pub_store(&ws->windows2[blockIdx.x][t], fine((uint32_t)clo2 * 128u + (uint32_t)t));
+        pub_store(&ws->windows2[blockIdx.x][kSelThreads + t], fine((uint32_t)clo2 * 128u + (uint32_t)(kSelThreads + t)));
+    }
     STAMP(0, 5);
     // publish: every storing wave drains, the workgroup meets, one lane draws the ticket
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -88,68 +118,69 @@ __device__ __forceinline__ bool seg_publish_and_ticket(const uint32_t* s_hist, u
 }
 
 // ---------------------------------------------------------------------------------------------
-// The resolve step inside the histogram launch (single device, 16-bit dtypes): run by the LAST workgroup to draw its ticket,
-// i.e. when every segment's coarse counts and window are in memory.  1024 threads; lds: the (finished) histogram's LDS.
-//   coarse bins (8 copies) -> scan -> the coarse bin C that holds the k-th key
-//   every segment's window slice for C (one agent-scope load per segment and fine bin, 32 per thread, all independent)
-//     -> their sum is the global fine histogram of C -> scan -> tau; the column of tau is every segment's tie count
-//     -> scan -> the cut segment
+// The resolve step inside the histogram launch (single device): run by the LAST workgroup to draw its ticket, i.e. when
+// every segment's coarse counts and window are in memory.  1024 threads; lds: the (finished) histogram's LDS.
+//   coarse bins (8 copies x NCB) -> scan -> the coarse bin C that holds the k_rem-th key of this digit
+//   every segment's window slice for C (16-byte cache-bypassing buffer loads, eight per thread, all independent)
+//     -> their sum is the global fine histogram of C -> scan -> the digit; on the last digit the column of tau is every
+//        segment's tie count -> scan -> the cut segment
+// The digit: keys with (key & pmask) == pval take part, their bin is (key >> shift) & (NCB * 128 - 1).  16-bit dtypes: one digit
+// (shift 0, NCB 256, last).  fp32: the high 15 bits (shift 16, NCB 256, not last), then the low 16 (shift 0, NCB 512, last).
 // A segment whose window does not cover C although it has magnitudes outside its window is counted again here (one
 // workgroup: slow, correct, and only for tensors whose segments live on wildly different scales).
 // ---------------------------------------------------------------------------------------------
-// value of `v` in the lowest lane whose `cond` holds (0 when none does), for every lane
-__device__ __forceinline__ uint32_t pick_lane(bool cond, uint32_t v)
-{
-    const unsigned long long m = __ballot(cond);
-    if (!m) return 0u;
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)__ffsll((long long)m) - 1));
-}
-
-template <int DT, bool FAST>
-__device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int64_t n_items, const SegGeom g, int64_t k, SelWs* ws, uint32_t* lds)
+template <int DT, bool FAST, int NCB>
+__device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int64_t n_items, const SegGeom g, SelWs* ws, uint32_t* lds,
+                                              uint32_t k_rem, int64_t k, int shift, uint32_t pmask, uint32_t pval, bool last, int clo2 = -1)
 {
     constexpr int VEC = Traits<DT>::VEC;
     constexpr int NC = BFPQ_SELECT_HIST_COPIES;
-    // ONE compute unit runs this while the rest of the chip idles (or waits for it): every instruction and every barrier
-    // counts.  The scans over 256 coarse bins, 128 fine bins and 256 segments are each done by ONE wave (DPP scan, a few
-    // values per lane); the 32 K window-slice words come as 16-byte cache-bypassing buffer loads, eight per thread, all in
-    // flight together, with no branch around them (per segment one LDS word says where its slice for C lies, or that it has none).
+    constexpr int PER = NCB / 64;
+    const uint32_t dmask = (uint32_t)NCB * 128u - 1u;
+    // ONE compute unit runs this while the rest of the chip idles: every instruction and every barrier counts.  The scans
+    // over the coarse bins, 128 fine bins and 256 segments are each done by ONE wave (DPP scan, a few values per lane); the
+    // 32 K window-slice words come as 16-byte cache-bypassing buffer loads, eight per thread, all in flight together, with no
+    // branch around them (per segment one LDS word says where its slice for C lies, or that it has none).
     uint32_t* s_off = lds;               // [256] word offset of the segment's slice inside ws->windows | bit 31: no slice
     uint32_t* s_tc = lds + 256;          // [256]
     uint32_t* s_fine = lds + 512;        // [32][128]
     uint32_t* s_r = lds + 4624;          // [16]
     uint32_t* s_h = lds + 4640;          // [128]
     uint32_t* s_segwin = lds + 4768;     // [256]
-    uint32_t* s_cv = lds + 5024;         // [256]
+    uint32_t* s_cv = lds + 5024;         // [NCB]
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     STAMP(2, 0);
     uint32_t cv = 0;
-    if (t < kCoarseBins) {
+    if (t < NCB) {
 #pragma unroll
         for (int c = 0; c < NC; c++) cv += pub_load(&ws->coarse[c][t]);
     }
     const uint32_t sw = t < g.G ? pub_load(&ws->seg_win[t]) : 0u;
     __syncthreads();                                         // (the histogram's LDS is dead from here on)
-    if (t < kMaxSeg) { s_segwin[t] = sw; s_cv[t] = cv; }
+    if (t < kMaxSeg) s_segwin[t] = sw;
+    if (t < NCB) s_cv[t] = cv;
     __syncthreads();
-    const uint32_t k_rem = (uint32_t)k;
-    if (wv == 0) {                                           // coarse bins: four per lane
-        const uint4 c4 = *reinterpret_cast<const uint4*>(&s_cv[4 * lane]);
-        const uint32_t mine = c4.x + c4.y + c4.z + c4.w;
+    if (wv == 0) {                                           // coarse bins: NCB / 64 per lane
+        uint32_t c[PER], mine = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { c[j] = s_cv[PER * lane + j]; mine += c[j]; }
         const uint32_t excl = wave_incl_scan(mine) - mine;
         const bool hit = mine && excl < k_rem && k_rem <= excl + mine;
-        uint32_t bin = 4u * lane, e = excl;
-        if (k_rem > e + c4.x) { e += c4.x; bin++; if (k_rem > e + c4.y) { e += c4.y; bin++; if (k_rem > e + c4.z) { e += c4.z; bin++; } } }
+        uint32_t bin = (uint32_t)(PER * lane), e = excl;
+#pragma unroll
+        for (int j = 0; j < PER - 1; j++) { if (k_rem > e + c[j]) { e += c[j]; bin = (uint32_t)(PER * lane + j + 1); } else break; }
         const uint32_t C0 = pick_lane(hit, bin), b0 = pick_lane(hit, e);
-        if (lane == 0) { s_r[0] = C0; s_r[1] = b0; s_r[2] = 0; s_r[3] = 0; s_r[4] = 0; }      // (k == 0: bin 0, nothing in front of it)
+        if (lane == 0) { s_r[0] = C0; s_r[1] = b0; s_r[2] = 0; s_r[3] = 0; s_r[4] = 0; }      // (k_rem == 0: bin 0, nothing in front of it)
     }
     __syncthreads();
     const uint32_t C = s_r[0], before = s_r[1];
     STAMP(2, 1);
-    for (int i = t; i < NC * kCoarseBins; i += kSelThreads) (&ws->coarse[0][0])[i] = 0u;     // zero for the next call
+    for (int i = t; i < NC * NCB; i += kSelThreads) ws->coarse[i / NCB][i % NCB] = 0u;        // zero for the next call
+    // (the second window, where there is one, sits at the same place in every segment: if it covers C, it answers for all of them)
+    const bool use2 = clo2 >= 0 && C - (uint32_t)clo2 < (uint32_t)(kWinBins / 128);
     // segments whose window cannot answer for C
     int miss = 0;
-    if (t < g.G) {
+    if (!use2 && t < g.G) {
         const uint32_t clo = (sw & 0x3fffffffu) >> 7;
         if (!(C - clo < (uint32_t)(kWinBins / 128)) && (sw >> 31)) miss = 1;
     }
@@ -167,7 +198,8 @@ __device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int
 #pragma unroll
                 for (int j = 0; j < VEC; j++) {
                     const uint32_t key = mag_key<DT>(r[j]);
-                    if ((FAST || it * VEC + j < numel) && (key >> 7) == C) atomicAdd(&s_h[key & 127u], 1u);
+                    const uint32_t bin = (key >> shift) & dmask;
+                    if ((FAST || it * VEC + j < numel) && (key & pmask) == pval && (bin >> 7) == C) atomicAdd(&s_h[bin & 127u], 1u);
                 }
             }
             __syncthreads();
@@ -182,7 +214,8 @@ __device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int
         if (t < g.G) {
             const uint32_t w = s_segwin[t], clo = (w & 0x3fffffffu) >> 7;
             const bool narrow = (w >> 30) & 1u;
-            if (narrow ? clo == C : C - clo < (uint32_t)(kWinBins / 128)) off = (uint32_t)t * kWinBins + (narrow ? 0u : (C - clo) * 128u);
+            if (use2) off = (uint32_t)(kMaxSeg + t) * kWinBins + (C - (uint32_t)clo2) * 128u;             // (windows2 lies directly behind windows)
+            else if (narrow ? clo == C : C - clo < (uint32_t)(kWinBins / 128)) off = (uint32_t)t * kWinBins + (narrow ? 0u : (C - clo) * 128u);
         }
         s_off[t] = off;
     }
@@ -190,7 +223,7 @@ __device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int
     STAMP(2, 2);
     // window slices: thread (sg, q) reads the fine bins 4q..4q+3 of C from the segments sg, sg + 32, ...
     typedef unsigned int v4u __attribute__((vector_size(16)));
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(&ws->windows[0][0], 0, (int)sizeof(ws->windows), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(&ws->windows[0][0], 0, (int)(sizeof(ws->windows) + sizeof(ws->windows2)), 0x00020000);
     const int sg = t >> 5, q = t & 31;
     v4u cnt[kMaxSeg / 32];
     uint32_t offs[kMaxSeg / 32];
@@ -216,17 +249,27 @@ __device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int
         const uint32_t excl = before + wave_incl_scan(mine) - mine;
         const bool hit = mine && excl < k_rem && k_rem <= excl + mine;
         const bool second = k_rem > excl + f0;
-        const uint32_t tau0 = pick_lane(hit, (C << 7) + 2u * lane + (second ? 1u : 0u));
+        const uint32_t dig0 = pick_lane(hit, (C << 7) + 2u * lane + (second ? 1u : 0u));
         const uint32_t run0 = pick_lane(hit, second ? excl + f0 : excl), ties0 = pick_lane(hit, second ? f1 : f0);
-        if (lane == 0) { s_r[2] = tau0; s_r[3] = run0; s_r[4] = ties0; }
+        if (lane == 0) { s_r[2] = dig0; s_r[3] = run0; s_r[4] = ties0; }
     }
     __syncthreads();
-    const uint32_t tau = s_r[2], run = s_r[3], ties = s_r[4];
+    const uint32_t digit = s_r[2], run = s_r[3], ties = s_r[4];
+    const uint32_t tau = pval | (digit << shift);
     const uint32_t need = k_rem - run;
     STAMP(2, 4);
+    if (!last) {                                             // more digits to come: the next launch reads the prefix
+        if (t == 0) {
+            bfpq_select_state* st = &ws->st;
+            st->prefix = tau; st->prefix_mask = pmask | (dmask << shift); st->k_rem = (int64_t)need; st->k = k; st->done = 0;
+            st->ties = (int64_t)ties;                        // (elements that share the prefix: the next digit's population)
+            ws->ticket = 0u;
+        }
+        return;
+    }
     // the column of tau: every segment's tie count
-    if (q == (int)((tau & 127u) >> 2)) {
-        const uint32_t comp = tau & 3u;
+    if (q == (int)((digit & 127u) >> 2)) {
+        const uint32_t comp = digit & 3u;
 #pragma unroll
         for (int j = 0; j < kMaxSeg / 32; j++) s_tc[sg + 32 * j] = comp == 0 ? cnt[j][0] : (comp == 1 ? cnt[j][1] : (comp == 2 ? cnt[j][2] : cnt[j][3]));
     }
@@ -252,7 +295,7 @@ __device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int
         STAMP(2, 5);
         if (lane == 0) {
             bfpq_select_state* st = &ws->st;
-            st->prefix = tau; st->prefix_mask = 0x7fffu; st->k_rem = (int64_t)need; st->tau = tau; st->done = 1;
+            st->prefix = tau; st->prefix_mask = pmask | (dmask << shift); st->k_rem = (int64_t)need; st->tau = tau; st->done = 1;
             st->need = (int64_t)need; st->ties = (int64_t)ties; st->k = k; st->tie_base = 0;
             st->flags = 1u; st->cut_lo = lo; st->cut_hi = hi; st->cut_within = within; st->cut_total = ctot;
             st->reserved = 0;

@@ -78,10 +78,13 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
     STAMP(0, 1);
     __syncthreads();
     STAMP(0, 2);
-    if (fuse) {                                             // (host: only with nbits == 15, first and last pass in one)
-        if (!seg_publish_and_ticket(s_hist, s_coarse, s_res, ws, k, numel_global)) return;
+    if (fuse) {                                             // (host: only with nbits == 15 and pass 0; 16-bit dtypes: the only digit, fp32: the high one)
+        coarse_from_lds<kCoarseBins, false>(s_hist, s_coarse);
+        __syncthreads();
+        const double frac = numel_global > 0 ? (double)k / (double)numel_global : 0.0;
+        if (!seg_publish_and_ticket<kCoarseBins>(s_coarse, s_res, ws, frac, [&](uint32_t b) { return s_hist[b]; })) return;
         STAMP(0, 6);
-        fused_resolve<DT, FAST>(in, numel, n_items, g, k, ws, s_hist);
+        fused_resolve<DT, FAST, kCoarseBins>(in, numel, n_items, g, ws, s_hist, (uint32_t)k, k, shift, 0u, 0u, last != 0);
         STAMP(0, 7);
         return;
     }
@@ -160,6 +163,128 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
     pub_store(&ws->windows[blockIdx.x][t], s_hist[lo + t]);
     pub_store(&ws->windows[blockIdx.x][kSelThreads + t], s_hist[lo + kSelThreads + t]);
     STAMP(0, 5);
+}
+
+// fp32, second (and last) digit of the single-device selection: the LOW 16 bits of the keys whose high 15 bits equal the prefix the
+// first launch left (bits >> 16 == tau_hi: normally ~0.5 % of the elements).  65 536 counters fit the LDS only as 16-bit halves
+// (128 KB): enough for what falls into one bin of the first digit, NOT for tie-heavy tensors -- so the workgroup proves that the
+// sum of its bins equals the number of elements it counted, and when the proof fails (a half wrapped, or carried into its
+// neighbour: either way the sum is off by a multiple of 65 535) it counts its segment again with 32-bit counters: the 512 coarse
+// sums in one sweep, the 2048 fine bins of its window in a second.  Publish / ticket / resolve as in the first launch, 512 coarse bins.
+template <bool FAST>
+__global__ void __launch_bounds__(kSelThreads) k_select_hist_lo16(const void* in, int64_t numel, SelWs* ws)
+{
+    constexpr int DT = BFPQ_F32;
+    constexpr int VEC = 4;
+    constexpr int NCB = 2 * kCoarseBins;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];          // 32 768 words = 65 536 16-bit bins
+    __shared__ __attribute__((aligned(16))) uint32_t s_coarse[NCB];
+    __shared__ uint32_t s_res[4];
+    __shared__ uint32_t s_part[16];
+    const int t = threadIdx.x;
+    for (int i = t; i < kFineBins / 4; i += kSelThreads) reinterpret_cast<uint4*>(s_hist)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const bfpq_select_state* st = &ws->st;
+    const uint32_t pmask = st->prefix_mask, pval = st->prefix;                 // (0x7fff0000, tau_hi << 16)
+    const uint32_t k_rem = (uint32_t)st->k_rem;
+    const int64_t k = st->k, pop = st->ties;                                   // pop: elements that share the prefix, over the whole tensor
+    const int64_t n_items = (numel + VEC - 1) / VEC;
+    const SegGeom g = seg_geom(n_items);
+    const int64_t i0 = (int64_t)blockIdx.x * g.L, i1 = i0 + g.L < n_items ? i0 + g.L : n_items;
+    uint32_t matched = 0;
+    {
+        int64_t item = i0 + t;
+        uint32_t cur[VEC], nxt[VEC];
+        sweep_load<DT, FAST>(in, item, n_items, numel, cur);
+        for (; item < i1; item += kSelThreads) {
+            sweep_load<DT, FAST>(in, item + kSelThreads, n_items, numel, nxt);
+#pragma unroll
+            for (int j = 0; j < VEC; j++) {
+                const uint32_t key = mag_key<DT>(cur[j]);
+                if ((FAST || item * VEC + j < numel) && (key & pmask) == pval) {
+                    atomicAdd(&s_hist[(key & 0xffffu) >> 1], (key & 1u) ? 0x10000u : 1u);
+                    matched++;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; j++) cur[j] = nxt[j];
+        }
+    }
+    __syncthreads();
+    coarse_from_lds<NCB, true>(s_hist, s_coarse);
+    uint32_t total_matched;
+    (void)block_excl_scan(matched, s_part, &total_matched);                    // (its barriers also complete s_coarse)
+    uint32_t csum = 0;
+    for (int i = t; i < NCB; i += kSelThreads) csum += s_coarse[i];
+    uint32_t total_bins;
+    (void)block_excl_scan(csum, s_part, &total_bins);
+    const bool exact = total_bins == total_matched;                            // (block-uniform)
+    const double frac = pop > 0 ? (double)k_rem / (double)pop : 0.0;
+    // A segment holds only a few hundred of these keys, so its own quantile is a noisy guess of where the threshold's low bits lie
+    // (sigma ~ 1500 of the 65 536 bins): a window around it misses too often.  The low 16 bits of real-valued data are spread almost
+    // evenly, so a SECOND window sits where the threshold then is, frac * 65 536 -- the same place in every segment; the window around
+    // the segment's own quantile stays for tensors whose low bits are anything but even (few distinct values: there all quantiles agree).
+    int clo2 = (int)(frac * 65536.0) / 128 - kWinBins / 256;
+    clo2 = clo2 < 0 ? 0 : (clo2 > NCB - kWinBins / 128 ? NCB - kWinBins / 128 : clo2);
+    bool is_last;
+    if (exact) {
+        is_last = seg_publish_and_ticket<NCB>(s_coarse, s_res, ws, frac, [&](uint32_t b) { return lds_bin<true>(s_hist, b); }, clo2);
+    } else {
+        // a 16-bit counter overflowed: the segment again, with 32-bit counters -- coarse sums, then the window's fine bins
+        uint32_t* s_win32 = s_hist;                                            // [2048] the window around the segment's own quantile, [2048] the second one
+        __syncthreads();
+        for (int i = t; i < NCB; i += kSelThreads) s_coarse[i] = 0;
+        for (int i = t; i < 2 * kWinBins; i += kSelThreads) s_win32[i] = 0;
+        __syncthreads();
+        auto sweep = [&](auto&& f) __attribute__((always_inline)) {
+            for (int64_t item = i0 + t; item < i1; item += kSelThreads) {
+                uint32_t r[VEC];
+                sweep_load<DT, FAST>(in, item, n_items, numel, r);
+#pragma unroll
+                for (int j = 0; j < VEC; j++) {
+                    const uint32_t key = mag_key<DT>(r[j]);
+                    if ((FAST || item * VEC + j < numel) && (key & pmask) == pval) f(key & 0xffffu);
+                }
+            }
+        };
+        sweep([&](uint32_t low) { atomicAdd(&s_coarse[low >> 7], 1u); });
+        __syncthreads();
+        // the window's position is decided inside seg_publish_and_ticket (s_res[0]); its fine bins are needed before it stores them:
+        // decide the position here the same way (quantile of the coarse sums), count, then publish
+        __shared__ uint32_t s_lo;
+        if (t < 64) {
+            constexpr int PER = NCB / 64;
+            uint32_t c[PER], mine = 0;
+#pragma unroll
+            for (int j = 0; j < PER; j++) { c[j] = s_coarse[t * PER + j]; mine += c[j]; }
+            const uint32_t incl = wave_incl_scan(mine);
+            const uint32_t seg_elems = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            uint64_t target = (uint64_t)((double)seg_elems * frac);
+            if (seg_elems && target >= seg_elems) target = seg_elems - 1;
+            const uint32_t excl = incl - mine;
+            const bool hit = mine && excl <= target && target < (uint64_t)excl + mine;
+            uint32_t e = excl;
+            int A = t * PER;
+#pragma unroll
+            for (int j = 0; j < PER - 1; j++) { if (target >= (uint64_t)e + c[j]) { e += c[j]; A = t * PER + j + 1; } else break; }
+            int clo = (int)pick_lane(hit, (uint32_t)A) - kWinBins / 256;
+            clo = clo < 0 ? 0 : (clo > NCB - kWinBins / 128 ? NCB - kWinBins / 128 : clo);
+            if (t == 0) s_lo = (uint32_t)clo * 128u;
+        }
+        __syncthreads();
+        const uint32_t lo = s_lo;
+        const uint32_t lo2 = (uint32_t)clo2 * 128u;
+        sweep([&](uint32_t low) {
+            if (low - lo < (uint32_t)kWinBins) atomicAdd(&s_win32[low - lo], 1u);
+            if (low - lo2 < (uint32_t)kWinBins) atomicAdd(&s_win32[kWinBins + low - lo2], 1u);
+        });
+        __syncthreads();
+        // (same coarse sums, same fraction: seg_publish_and_ticket places the first window where `lo` is; it asks for bins of either window)
+        is_last = seg_publish_and_ticket<NCB>(s_coarse, s_res, ws, frac, [&](uint32_t b) {
+            return b - lo < (uint32_t)kWinBins ? s_win32[b - lo] : s_win32[kWinBins + b - lo2]; }, clo2);
+    }
+    if (!is_last) return;
+    fused_resolve<DT, FAST, NCB>(in, numel, n_items, g, ws, s_hist, k_rem, k, 0, pmask, pval, true, clo2);
 }
 
 // Launch 2 of the launch-pair form (multi-GPU: between them the all-gather of the histograms; fp32: three pairs): one
@@ -373,11 +498,12 @@ static int launch_select_hist(const void* in, int64_t numel, int dtype, int pass
 {
     int shift, nbits;
     select_digit(dtype, pass, &shift, &nbits);
+    int first = pass == 0, last = pass == bfpq_select_passes(dtype) - 1;
+    if (fuse == 2) { shift = 16; nbits = 15; first = 1; last = 0; }      // fp32, single device: the high 15 bits of the key, resolved in the launch
     const size_t lds = sizeof(uint32_t) << nbits;
     const int vec = dtype_vec(dtype);
     const SegGeom g = seg_geom((numel + vec - 1) / vec);
     const bool fast = (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && numel % vec == 0;
-    const int first = pass == 0, last = pass == bfpq_select_passes(dtype) - 1;
     hipStream_t s = (hipStream_t)stream;
     SelWs* w = (SelWs*)ws;
 #define BFPQ_SH(DT, F) do { \
@@ -434,13 +560,24 @@ int bfpq_select(const void* in, int64_t numel, int dtype, int64_t k, void* ws, v
     if (numel >= ((int64_t)1 << 32)) return BFPQ_E_UNSUPPORTED;
     if (numel == 0) return 0;
     if (dtype != BFPQ_F32) return launch_select_hist(in, numel, dtype, 0, k, numel, ws, nullptr, 1, stream);
-    for (int p = 0; p < 3; p++) {
-        int rc = launch_select_hist(in, numel, dtype, p, k, numel, ws, nullptr, 0, stream);
-        if (rc) return rc;
-        rc = bfpq_select_resolve(in, numel, dtype, p, k, nullptr, 1, 0, ws, nullptr, stream);
-        if (rc) return rc;
+    // fp32: two digits, two launches, each ending in its own resolve step -- the high 15 bits of the key (the 16-bit dtypes' kernel on
+    // bits >> 16), then the low 16 bits of the keys that share that prefix (16-bit LDS counters, see k_select_hist_lo16)
+    int rc = launch_select_hist(in, numel, dtype, 0, k, numel, ws, nullptr, 2, stream);
+    if (rc) return rc;
+    const size_t lds = sizeof(uint32_t) * kFineBins;
+    const SegGeom g = seg_geom((numel + 3) / 4);
+    const bool fast = (reinterpret_cast<uintptr_t>(in) & 15u) == 0 && numel % 4 == 0;
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t err = hipFuncSetAttribute((const void*)k_select_hist_lo16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err == hipSuccess) err = hipFuncSetAttribute((const void*)k_select_hist_lo16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (err != hipSuccess) return (int)err;
+        attr_set = true;
     }
-    return 0;
+    if (fast) hipLaunchKernelGGL((k_select_hist_lo16<true>), dim3(g.G), dim3(kSelThreads), lds, s, in, numel, (SelWs*)ws);
+    else hipLaunchKernelGGL((k_select_hist_lo16<false>), dim3(g.G), dim3(kSelThreads), lds, s, in, numel, (SelWs*)ws);
+    return (int)hipGetLastError();
 }
 
 int bfpq_select_reset(void* ws, void* stream)

@@ -458,8 +458,8 @@ class SelectWorkspace:
 
 def select_threshold(t, k, ws, numel_global=None, allgather=None):
     """radix-select the k-th smallest magnitude of t (device tensor) and leave threshold + tie bookkeeping in ws.
-    Single device: bfpq_select -- ONE launch for a 16-bit dtype (the histogram launch's last workgroup resolves), three
-    launch pairs for fp32.
+    Single device: bfpq_select -- ONE launch for a 16-bit dtype (the histogram launch's last workgroup resolves), two for
+    fp32 (the high 15 bits of the key, then the low 16).
     Multi-GPU: t is this rank's slab, k / numel_global are global, and allgather(hist) -> (hist_all [R, entries], R, rank)
     gathers the per-rank histograms (the one exchange of the path; an empty slab still joins it)."""
     require_device_tensor(t)
@@ -478,8 +478,7 @@ def select_threshold(t, k, ws, numel_global=None, allgather=None):
             if ng != n:
                 raise ValueError("select_threshold: numel_global without an allgather")
             check(L.bfpq_select(_ptr(src), n, code, int(k), _ptr(ws.ws), st), "bfpq_select")
-            ws.dirty = code == F32                         # (its histograms inside ws are cleared by the apply launch)
-            return
+            return                                         # (leaves the workspace ready for the next call by itself)
         for p in range(L.bfpq_select_passes(code)):
             hist = ws.ext_hist()                           # zero on entry: resolve clears it again after the gather
             check(L.bfpq_select_hist(_ptr(src) if n else null, n, code, p, int(k), ng, _ptr(ws.ws), _ptr(hist), st), "bfpq_select_hist")
