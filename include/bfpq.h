@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define BFPQ_VERSION 3
+#define BFPQ_VERSION 4
 
 enum { BFPQ_F32 = 0, BFPQ_F16 = 1, BFPQ_BF16 = 2 };
 
@@ -119,6 +119,14 @@ int bfpq_fake_quantize(const bfpq_plan* plan_host, const void* in_dev, void* out
  * shape the single-pass kernel does not take (ragged rows, M = 8, ...) are handled one by one inside the call. */
 typedef struct bfpq_tensor_desc { const void* in_dev; void* out_dev; int64_t rows, cols; int apply_nm; int reserved; } bfpq_tensor_desc;
 int bfpq_fake_quantize_batched(const bfpq_plan* plan_host, const bfpq_tensor_desc* descs_host, int n, void* stream);
+/* The same list over TWO streams (ABI 4).  Inside either call a tensor of 24 MB or more gets a launch of its own (the list kernel only
+ * pays where a launch of its own would be mostly ramp and tail); with aux_stream != NULL those launches alternate between `stream`
+ * and `aux_stream`, so that the tail of one tensor's launch runs beside the ramp of the next (64 x [4096,11008] bf16 2:4 -> HBFP4:
+ * 29.5-30.2 us per tensor against 31.9-33.4 on one stream and 35.7-37.0 in the list kernel).  aux_stream waits for what `stream` held
+ * at the call and `stream` waits for aux_stream before the call returns (fork / join by events: hipGraph-capturable from `stream`).
+ * The tensors of one list must not overlap one another (they are processed side by side).  bfpq_fake_quantize_batched(...) is
+ * bfpq_fake_quantize_list(..., stream, NULL). */
+int bfpq_fake_quantize_list(const bfpq_plan* plan_host, const bfpq_tensor_desc* descs_host, int n, void* stream, void* aux_stream);
 
 /* returns 1 if bfpq_quantize_nm would take the single-pass fused kernel for this problem */
 int bfpq_is_fused(int64_t rows, int64_t cols, int dtype, int block_size, int N, int M);

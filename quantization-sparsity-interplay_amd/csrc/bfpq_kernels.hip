@@ -741,10 +741,44 @@ int bfpq_fake_quantize(const bfpq_plan* p, const void* in, void* out, int64_t ro
                             p->sparsify_first, 0, 0, p->exp_win_dev, p->nm_lut_dev, nullptr, stream);
 }
 
-int bfpq_fake_quantize_batched(const bfpq_plan* p, const bfpq_tensor_desc* descs, int n, void* stream)
+// A tensor of at least this many input bytes gets a launch of its own inside a list call (k_fused_flat), alternating between the
+// caller's stream and the aux stream; smaller ones share list launches (k_fused_batched).  Measured on [4096,11008] / [4096,4096] /
+// [1024,4096] bf16 2:4 -> HBFP4, 64 tensors per pass (tools_dev/ab_footprint.py, us per tensor): list kernel 35.7-37.0 / 11.4-12.9 /
+// 2.6-3.1; one launch per tensor on one stream 31.9-33.4 / 13.7 / 5.6-5.9; one launch per tensor over two streams 29.5-30.2 / 11.6 /
+// 5.4-5.5.  The list kernel's workgroups drift apart over a long list (no launch boundary pulls the sweep's front together again)
+// and it wins only where a launch of its own would be mostly ramp and tail; two streams let the tail of one tensor's launch run
+// beside the ramp of the next one.
+constexpr int64_t kListOwnLaunchBytes = (int64_t)24 << 20;
+
+int bfpq_fake_quantize_list(const bfpq_plan* p, const bfpq_tensor_desc* descs, int n, void* stream, void* aux_stream)
 {
     if (!p || (n > 0 && !descs) || n < 0) return BFPQ_E_ARG;
     hipStream_t s = (hipStream_t)stream;
+    hipStream_t sa = (hipStream_t)aux_stream;
+    if (sa == s) sa = nullptr;
+    // fork / join around whatever goes to the aux stream (hipGraph-capturable from `stream`); the fork is taken at the first
+    // tensor that gets a launch of its own, so a list of small tensors costs nothing extra
+    hipEvent_t ev = nullptr;
+    bool forked = false;
+    int turn = 0;                                                          // which stream takes the next own-launch tensor
+    auto own_stream = [&]() -> hipStream_t {
+        if (!sa) return s;
+        if (!forked) {
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, s) != hipSuccess ||
+                hipStreamWaitEvent(sa, ev, 0) != hipSuccess) { if (ev) { (void)hipEventDestroy(ev); ev = nullptr; } sa = nullptr; return s; }
+            forked = true;
+        }
+        return (turn++ & 1) ? sa : s;
+    };
+    auto join = [&](int rc) -> int {
+        if (forked) {
+            hipError_t e = hipEventRecord(ev, sa);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s, ev, 0);
+            if (e != hipSuccess && !rc) rc = (int)e;
+        }
+        if (ev) (void)hipEventDestroy(ev);
+        return rc;
+    };
     const int dtype = p->dtype;
     if (dtype < 0 || dtype > 2 || p->block_size < 0 || (p->block_size > 0 && !p->exp_win_dev)) return BFPQ_E_ARG;
     const bool any_nm_cfg = p->M > 0;
@@ -770,33 +804,38 @@ int bfpq_fake_quantize_batched(const bfpq_plan* p, const bfpq_tensor_desc* descs
     };
     for (int i = 0; i < n; i++) {
         const bfpq_tensor_desc& d = descs[i];
-        if (d.rows < 0 || d.cols < 0) return BFPQ_E_ARG;
+        if (d.rows < 0 || d.cols < 0) return join(BFPQ_E_ARG);
         if (d.rows * d.cols == 0) continue;
-        if (!d.in_dev || !d.out_dev) return BFPQ_E_ARG;
+        if (!d.in_dev || !d.out_dev) return join(BFPQ_E_ARG);
         const bool nm = any_nm_cfg && d.apply_nm != 0;
         const int N = nm ? p->N : 0, M = nm ? p->M : 0;
-        if (p->block_size == 0 && M == 0) return BFPQ_E_ARG;                // identity: the caller keeps its tensor
+        if (p->block_size == 0 && M == 0) return join(BFPQ_E_ARG);         // identity: the caller keeps its tensor
         const bool aligned = ((reinterpret_cast<uintptr_t>(d.in_dev) | reinterpret_cast<uintptr_t>(d.out_dev)) & 15u) == 0;
         const bool ok = aligned && (M == 0 || (M == 4 && p->nm_lut_dev)) && p->block_size > 0 &&
                         fused_shape_ok(d.rows, d.cols, dtype, p->block_size, N, M) &&
                         (d.rows * d.cols / dtype_vec(dtype)) % kThreads == 0 &&          // whole chunks of 256 lane items only
-
                         (d.rows * d.cols / dtype_vec(dtype) + kThreads - 1) / kThreads < ((int64_t)1 << 31);
-        if (!ok) {
+        const bool own = d.rows * d.cols * dtype_size(dtype) >= kListOwnLaunchBytes;
+        if (!ok || own) {
             const int rc = bfpq_quantize_nm(d.in_dev, d.out_dev, nullptr, nullptr, d.rows, d.cols, dtype, p->block_size, p->mant_bits, p->epsilon,
-                                            N, M, p->sparsify_first, 0, 0, p->exp_win_dev, p->nm_lut_dev, nullptr, stream);
-            if (rc) return rc;
+                                            N, M, p->sparsify_first, 0, 0, p->exp_win_dev, p->nm_lut_dev, nullptr, own ? (void*)own_stream() : stream);
+            if (rc) return join(rc);
             continue;
         }
         const int64_t items = d.rows * d.cols / dtype_vec(dtype);
         const int64_t chunks = (items + kThreads - 1) / kThreads;
-        if (b.n == kMaxBatch || (int64_t)b.total_chunks + chunks >= ((int64_t)1 << 32)) { const int rc = flush(); if (rc) return rc; }
+        if (b.n == kMaxBatch || (int64_t)b.total_chunks + chunks >= ((int64_t)1 << 32)) { const int rc = flush(); if (rc) return join(rc); }
         BatchDesc& o = b.d[b.n++];
         o.in = d.in_dev; o.out = d.out_dev; o.n_items = items; o.chunk0 = b.total_chunks; o.flags = nm ? 1u : 0u;
         b.total_chunks += (uint32_t)chunks;
         batch_has_nm = batch_has_nm || nm;
     }
-    return flush();
+    return join(flush());
+}
+
+int bfpq_fake_quantize_batched(const bfpq_plan* p, const bfpq_tensor_desc* descs, int n, void* stream)
+{
+    return bfpq_fake_quantize_list(p, descs, n, stream, nullptr);
 }
 
 int bfpq_nm_sparsify(const void* in, void* out, int64_t rows, int64_t cols, int dtype, int N, int M,

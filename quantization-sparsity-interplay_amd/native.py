@@ -76,6 +76,7 @@ def load_library():
         L.bfpq_quantize_nm.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, dbl, i32, i32, i32, i32, u64, vp, vp, vp, vp]
         L.bfpq_fake_quantize.argtypes = [vp, vp, vp, i64, i64, vp]
         L.bfpq_fake_quantize_batched.argtypes = [vp, vp, i32, vp]
+        L.bfpq_fake_quantize_list.argtypes = [vp, vp, i32, vp, vp]
         L.bfpq_is_fused.argtypes = [i64, i64, i32, i32, i32, i32]
         L.bfpq_nm_sparsify.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp]
         L.bfpq_select_passes.argtypes = [i32]
@@ -103,7 +104,7 @@ def load_library():
         L.bfpq_hbfp_linear_mx8.argtypes = [vp, vp, vp, vp, vp, vp, i64, i64, i64, i32, vp]
         L.bfpq_hbfp_linear_mx8_parts.argtypes = [i64, i64, i64]
         L.bfpq_hbfp_linear_mx8_splitk.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, i64, i32, vp]
-        for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_is_fused", "bfpq_nm_sparsify",
+        for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_fake_quantize_list", "bfpq_is_fused", "bfpq_nm_sparsify",
                      "bfpq_select_passes", "bfpq_select", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
                      "bfpq_prune_quantize", "bfpq_prune_quantize_batched",
                      "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize", "bfpq_hbfp_linear_slices",
@@ -116,7 +117,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_mx8_parts", "bfpq_hbfp_linear_mx8_splitk", "bfpq_quantize_mx8", "bfpq_mx8_from_hbfp", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_select_ws_bytes", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24",
-                    "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_is_fused", "bfpq_nm_sparsify",
+                    "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_fake_quantize_list", "bfpq_is_fused", "bfpq_nm_sparsify",
                     "bfpq_select_passes", "bfpq_select", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
                     "bfpq_prune_quantize", "bfpq_prune_quantize_batched",
                     "bfpq_threshold_apply", "bfpq_quantize_threshold")
@@ -353,9 +354,10 @@ class FastQuant:
         if k:
             plan = self._plan(dt, dev)
             with torch.cuda.device(dev):
-                rc = load_library().bfpq_fake_quantize_batched(plan[1], ctypes.addressof(descs), k, torch.cuda.current_stream(dev).cuda_stream)
+                rc = load_library().bfpq_fake_quantize_list(plan[1], ctypes.addressof(descs), k, torch.cuda.current_stream(dev).cuda_stream,
+                                                            aux_stream(dev).cuda_stream if k > 1 else None)
             if rc:
-                check(rc, "bfpq_fake_quantize_batched")
+                check(rc, "bfpq_fake_quantize_list")
         return res
 
 
@@ -398,8 +400,10 @@ class PreparedList:
             self._keep.append(t)
         self._bound = [(t, t.data_ptr(), t.numel()) for t in self._keep]
         self._plan = fq._plan(self.dtype, self.device) if self._k else None
-        self._fn = load_library().bfpq_fake_quantize_batched
+        self._fn = load_library().bfpq_fake_quantize_list
         self._addr = ctypes.addressof(self._descs)
+        # (large tensors of the list get launches of their own, alternating between the current stream and this one)
+        self._aux = aux_stream(self.device).cuda_stream if self._k > 1 else None
 
     def _rebind(self):
         """descriptor j reads self._keep[j]: follow tensors whose storage moved since they were bound"""
@@ -419,12 +423,12 @@ class PreparedList:
             dev = self.device
             if torch.cuda.current_device() != dev.index:
                 with torch.cuda.device(dev):
-                    rc = self._fn(self._plan[1], self._addr, self._k, torch.cuda.current_stream(dev).cuda_stream)
+                    rc = self._fn(self._plan[1], self._addr, self._k, torch.cuda.current_stream(dev).cuda_stream, self._aux)
             else:
                 rc = self._fn(self._plan[1], self._addr, self._k,
-                              _raw_stream(dev.index) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream)
+                              _raw_stream(dev.index) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream, self._aux)
             if rc:
-                check(rc, "bfpq_fake_quantize_batched")
+                check(rc, "bfpq_fake_quantize_list")
         return self.outputs
 
 

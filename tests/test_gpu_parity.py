@@ -35,7 +35,7 @@ def synth(rows, cols, dtype, scale=0.02, seed=1234):
 
 def test_native_library_is_the_one_running():
     assert torch.cuda.is_available()
-    assert pkg.load_library().bfpq_version() == 3
+    assert pkg.load_library().bfpq_version() == 4
     import os
     maps = open(f"/proc/{os.getpid()}/maps").read()
     assert "libbfpq.so" in maps
@@ -1200,6 +1200,52 @@ def test_batched_list_equals_per_tensor_and_oracle(dname):
         finally:
             bfp_ops.FUSE_OPERAND_PAIR = True
     assert torch.equal(y, y2)
+
+
+def test_list_with_large_tensors_over_two_streams():
+    """bfpq_fake_quantize_list: tensors of 24 MB or more get launches of their own, alternating between the caller's stream and
+    the side stream; small ones share list launches.  A mixed list (large, small, ragged, large) == the per-tensor call, eagerly,
+    captured into a hipGraph and replayed on new data, from a non-default stream, and through the one-stream C entry point."""
+    dt = torch.bfloat16
+    shapes = [(4096, 4096), (64, 256), (3072, 4096), (5, 100), (2048, 8192), (768, 768), (4096, 3072)]
+    c = cfg(w_sparsity=True)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    xs = [(torch.randn(r, k, generator=g, device=DEV) * 0.02).to(dt) for r, k in shapes]
+    want = [bfp_ops.float_to_bfp_blocked(x, **c, identifier='w').clone() for x in xs]
+    for i in (0, 2):                                                     # (the large ones against the oracle on a slab)
+        assert_bits_equal(bits(want[i][:64].cpu()), bits(O.float_to_bfp_blocked(xs[i][:64].cpu(), **c, identifier='w')), dt, f"large #{i} vs oracle")
+    got = bfp_ops.float_to_bfp_blocked_many(xs, identifier='w', **c)
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), f"eager list #{i}"
+    prep = bfp_ops.PreparedMany(xs, identifier='w', **c)
+    bound = prep.run()                                                   # (the list's own output tensors, rewritten by every run)
+    for y in bound:
+        y.zero_()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        prep.run()
+    with torch.no_grad():
+        for x in xs:
+            x.mul_(1.3)
+    want2 = [bfp_ops.float_to_bfp_blocked(x, **c, identifier='w').clone() for x in xs]
+    gr.replay()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(bound, want2)):
+        assert torch.equal(a, b), f"graph replay #{i}"
+    s1 = torch.cuda.Stream()
+    s1.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s1):
+        outs = [y.clone() for y in prep.run()]
+    torch.cuda.current_stream().wait_stream(s1)
+    for i, (a, b) in enumerate(zip(outs, want2)):
+        assert torch.equal(a, b), f"side-stream caller #{i}"
+    # the one-stream entry point (aux_stream NULL): same results
+    f = native.FastQuant(64, 3, 1e-8, 2, 4, True)
+    pl = native.PreparedList(f, xs)
+    pl._aux = None
+    for i, (a, b) in enumerate(zip(pl.run(), want2)):
+        assert torch.equal(a, b), f"one stream #{i}"
 
 
 def test_prepared_list_reruns_in_place():

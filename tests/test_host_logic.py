@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(native.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.bfpq_version() == 3
+    assert L.bfpq_version() == 4
     assert b"invalid" in L.bfpq_error_string(-1)
 
 
