@@ -119,14 +119,16 @@ int bfpq_fake_quantize(const bfpq_plan* plan_host, const void* in_dev, void* out
  * shape the single-pass kernel does not take (ragged rows, M = 8, ...) are handled one by one inside the call. */
 typedef struct bfpq_tensor_desc { const void* in_dev; void* out_dev; int64_t rows, cols; int apply_nm; int reserved; } bfpq_tensor_desc;
 int bfpq_fake_quantize_batched(const bfpq_plan* plan_host, const bfpq_tensor_desc* descs_host, int n, void* stream);
-/* The same list over TWO streams (ABI 4).  Inside either call a tensor of 24 MB or more gets a launch of its own (the list kernel only
- * pays where a launch of its own would be mostly ramp and tail); with aux_stream != NULL those launches alternate between `stream`
- * and `aux_stream`, so that the tail of one tensor's launch runs beside the ramp of the next (64 x [4096,11008] bf16 2:4 -> HBFP4:
- * 29.5-30.2 us per tensor against 31.9-33.4 on one stream and 35.7-37.0 in the list kernel).  aux_stream waits for what `stream` held
- * at the call and `stream` waits for aux_stream before the call returns (fork / join by events: hipGraph-capturable from `stream`).
- * The tensors of one list must not overlap one another (they are processed side by side).  bfpq_fake_quantize_batched(...) is
- * bfpq_fake_quantize_list(..., stream, NULL). */
-int bfpq_fake_quantize_list(const bfpq_plan* plan_host, const bfpq_tensor_desc* descs_host, int n, void* stream, void* aux_stream);
+/* The same list over several LANES (ABI 4): the caller's stream and up to 7 aux streams.  Inside either call a tensor of 24 MB or more
+ * gets a launch of its own (the list kernel only pays where a launch of its own would be mostly ramp and tail); with aux streams those
+ * launches are spread over the lanes -- each to the lane that has been given the fewest bytes so far -- so that the tail of one
+ * tensor's launch runs beside the ramp of another's (64 x [4096,11008] bf16 2:4 -> HBFP4, us per tensor: one aux stream 29.5-30.2,
+ * none 31.9-33.4, the list kernel 35.7-37.0; LLaMA-7B's 224 weights 4.07 ms against 5.31; more than one aux stream buys nothing here).
+ * The aux lanes wait for what `stream` held at the call and `stream` waits for them before the call returns (one fork, one join, no
+ * event between the lanes: hipGraph-capturable from `stream`).  The tensors of one list must not overlap one another (they are
+ * processed side by side).  bfpq_fake_quantize_batched(...) is bfpq_fake_quantize_list(..., stream, NULL, 0). */
+int bfpq_fake_quantize_list(const bfpq_plan* plan_host, const bfpq_tensor_desc* descs_host, int n, void* stream,
+                            void* const* aux_streams_host, int n_aux);
 
 /* returns 1 if bfpq_quantize_nm would take the single-pass fused kernel for this problem */
 int bfpq_is_fused(int64_t rows, int64_t cols, int dtype, int block_size, int N, int M);
@@ -197,14 +199,19 @@ int bfpq_quantize_threshold(const void* in_dev, void* out_deq_dev, void* out_cod
  * bfpq_select + bfpq_quantize_threshold behind one call (two launches for a 16-bit dtype; the tensor is read by both). */
 int bfpq_prune_quantize(const void* in_dev, void* out_dev, int64_t rows, int64_t cols, int dtype, int block_size, int mant_bits,
                         double epsilon, int64_t k, const uint8_t* exp_win_dev, void* ws_dev, void* stream);
-/* The same op for a LIST of tensors -- every Linear weight of a model (BASELINE config 4) -- pipelined over two streams: the
- * selection launch of tensor i + 1 runs on `stream` while the prune + quantize launch of tensor i runs on `aux_stream`, so the
- * selection's serial tail (publishing, the ticket, the resolve step: ~10 us in which the memory system idles) is covered by the
- * other tensor's streaming.  ws_devs: n_ws >= 2 caller-owned workspaces (BFPQ_SELECT_WS_BYTES each, zeroed once), used in
- * rotation; events order their reuse.  aux_stream == NULL (or n_ws < 2): everything on `stream`, tensor by tensor.
- * On return `stream` waits for everything issued on aux_stream (fork / join: hipGraph-capturable from `stream`).
- * Creates and destroys a handful of hipEvents per call; launches only, no synchronisation. */
+/* The same op for a LIST of tensors -- every Linear weight of a model (BASELINE config 4) -- over independent LANES (ABI 4): the
+ * caller's stream and up to 7 aux streams, a workspace per lane (ws_devs: n_ws distinct caller-owned workspaces, BFPQ_SELECT_WS_BYTES
+ * each, zeroed once; lanes used = min(1 + n_aux, n_ws)).  A tensor's two launches go back to back to the lane that has been given the
+ * fewest bytes so far; nothing orders the lanes against one another, so a lane's serial tail (publishing, the ticket, the resolve
+ * step, the kernel boundary: ~13 us in which that lane moves no data) is covered by the other lanes' streaming.  LLaMA-13B, all 280
+ * weights, bf16: one lane 16.8 ms, two 14.2, three 12.7, four 12.5.  The aux lanes wait for what `stream` held at the call and
+ * `stream` waits for them before the call returns (one fork, one join: hipGraph-capturable from `stream`).  The tensors of one list
+ * must not overlap one another.  Creates and destroys a handful of hipEvents per call; launches only, no synchronisation.
+ * bfpq_prune_quantize_batched (ABI 3) is the same call with at most one aux stream. */
 typedef struct bfpq_prune_desc { const void* in_dev; void* out_dev; int64_t rows, cols; int64_t k; } bfpq_prune_desc;
+int bfpq_prune_quantize_list(const bfpq_prune_desc* descs_host, int n, int dtype, int block_size, int mant_bits, double epsilon,
+                             const uint8_t* exp_win_dev, void* const* ws_devs_host, int n_ws, void* stream,
+                             void* const* aux_streams_host, int n_aux);
 int bfpq_prune_quantize_batched(const bfpq_prune_desc* descs_host, int n, int dtype, int block_size, int mant_bits, double epsilon,
                                 const uint8_t* exp_win_dev, void* const* ws_devs_host, int n_ws, void* stream, void* aux_stream);
 

@@ -741,8 +741,8 @@ int bfpq_fake_quantize(const bfpq_plan* p, const void* in, void* out, int64_t ro
                             p->sparsify_first, 0, 0, p->exp_win_dev, p->nm_lut_dev, nullptr, stream);
 }
 
-// A tensor of at least this many input bytes gets a launch of its own inside a list call (k_fused_flat), alternating between the
-// caller's stream and the aux stream; smaller ones share list launches (k_fused_batched).  Measured on [4096,11008] / [4096,4096] /
+// A tensor of at least this many input bytes gets a launch of its own inside a list call (k_fused_flat), on one of the call's lanes
+// (the caller's stream and its aux streams); smaller ones share list launches (k_fused_batched).  Measured on [4096,11008] / [4096,4096] /
 // [1024,4096] bf16 2:4 -> HBFP4, 64 tensors per pass (tools_dev/ab_footprint.py, us per tensor): list kernel 35.7-37.0 / 11.4-12.9 /
 // 2.6-3.1; one launch per tensor on one stream 31.9-33.4 / 13.7 / 5.6-5.9; one launch per tensor over two streams 29.5-30.2 / 11.6 /
 // 5.4-5.5.  The list kernel's workgroups drift apart over a long list (no launch boundary pulls the sweep's front together again)
@@ -750,35 +750,69 @@ int bfpq_fake_quantize(const bfpq_plan* p, const void* in, void* out, int64_t ro
 // beside the ramp of the next one.
 constexpr int64_t kListOwnLaunchBytes = (int64_t)24 << 20;
 
-int bfpq_fake_quantize_list(const bfpq_plan* p, const bfpq_tensor_desc* descs, int n, void* stream, void* aux_stream)
-{
-    if (!p || (n > 0 && !descs) || n < 0) return BFPQ_E_ARG;
-    hipStream_t s = (hipStream_t)stream;
-    hipStream_t sa = (hipStream_t)aux_stream;
-    if (sa == s) sa = nullptr;
-    // fork / join around whatever goes to the aux stream (hipGraph-capturable from `stream`); the fork is taken at the first
-    // tensor that gets a launch of its own, so a list of small tensors costs nothing extra
-    hipEvent_t ev = nullptr;
-    bool forked = false;
-    int turn = 0;                                                          // which stream takes the next own-launch tensor
-    auto own_stream = [&]() -> hipStream_t {
-        if (!sa) return s;
-        if (!forked) {
-            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, s) != hipSuccess ||
-                hipStreamWaitEvent(sa, ev, 0) != hipSuccess) { if (ev) { (void)hipEventDestroy(ev); ev = nullptr; } sa = nullptr; return s; }
-            forked = true;
+// Lanes of a list call: the caller's stream (lane 0) and up to kMaxLanes - 1 aux streams.  Every tensor that gets launches of its
+// own goes, whole, to the lane that has been given the fewest bytes so far; the lanes run side by side without any event between
+// them -- one fork (the aux lanes wait for what the caller's stream held at the call), taken when the first tensor goes to an aux
+// lane, and one join (the caller's stream waits for every aux lane that was used).  hipGraph-capturable from the caller's stream.
+constexpr int kMaxLanes = 8;
+struct Lanes {
+    hipStream_t s[kMaxLanes];
+    int64_t bytes[kMaxLanes];
+    bool used[kMaxLanes];
+    int n;
+    hipEvent_t fork;
+    int err;
+    Lanes(void* stream, void* const* aux, int n_aux) : n(1), fork(nullptr), err(0)
+    {
+        s[0] = (hipStream_t)stream;
+        for (int i = 0; aux && i < n_aux && n < kMaxLanes; i++) {
+            hipStream_t a = (hipStream_t)aux[i];
+            bool dup = !a;
+            for (int j = 0; j < n; j++) dup = dup || s[j] == a;
+            if (!dup) s[n++] = a;
         }
-        return (turn++ & 1) ? sa : s;
-    };
-    auto join = [&](int rc) -> int {
-        if (forked) {
-            hipError_t e = hipEventRecord(ev, sa);
-            if (e == hipSuccess) e = hipStreamWaitEvent(s, ev, 0);
-            if (e != hipSuccess && !rc) rc = (int)e;
+        for (int i = 0; i < kMaxLanes; i++) { bytes[i] = 0; used[i] = false; }
+    }
+    int pick(int64_t b)                                                    // lane for a tensor of b bytes
+    {
+        // the fork is recorded in front of the call's FIRST own launch, whichever lane takes it: recorded later, it would also make
+        // the aux lanes wait for the tensors lane 0 has been given in the meantime
+        if (n > 1 && !fork && (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess || hipEventRecord(fork, s[0]) != hipSuccess)) {
+            if (fork) { (void)hipEventDestroy(fork); fork = nullptr; }
+            n = 1;                                                         // (no event: everything on the caller's stream)
         }
-        if (ev) (void)hipEventDestroy(ev);
+        int l = 0;
+        for (int i = 1; i < n; i++) if (bytes[i] < bytes[l]) l = i;
+        if (l > 0 && !used[l]) {
+            if (hipStreamWaitEvent(s[l], fork, 0) != hipSuccess) l = 0;
+            else used[l] = true;
+        }
+        bytes[l] += b;
+        return l;
+    }
+    int join(int rc)                                                       // also on an error path: a capture must not be left forked
+    {
+        for (int l = 1; l < n; l++) {
+            if (!used[l]) continue;
+            hipEvent_t e = nullptr;
+            hipError_t h = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            if (h == hipSuccess) h = hipEventRecord(e, s[l]);
+            if (h == hipSuccess) h = hipStreamWaitEvent(s[0], e, 0);
+            if (e) (void)hipEventDestroy(e);
+            if (h != hipSuccess && !rc) rc = (int)h;
+        }
+        if (fork) (void)hipEventDestroy(fork);
+        fork = nullptr;
         return rc;
-    };
+    }
+};
+
+int bfpq_fake_quantize_list(const bfpq_plan* p, const bfpq_tensor_desc* descs, int n, void* stream, void* const* aux_streams, int n_aux)
+{
+    if (!p || (n > 0 && !descs) || n < 0 || n_aux < 0 || (n_aux > 0 && !aux_streams)) return BFPQ_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    Lanes lanes(stream, aux_streams, n_aux);
+    auto join = [&](int rc) { return lanes.join(rc); };
     const int dtype = p->dtype;
     if (dtype < 0 || dtype > 2 || p->block_size < 0 || (p->block_size > 0 && !p->exp_win_dev)) return BFPQ_E_ARG;
     const bool any_nm_cfg = p->M > 0;
@@ -818,7 +852,8 @@ int bfpq_fake_quantize_list(const bfpq_plan* p, const bfpq_tensor_desc* descs, i
         const bool own = d.rows * d.cols * dtype_size(dtype) >= kListOwnLaunchBytes;
         if (!ok || own) {
             const int rc = bfpq_quantize_nm(d.in_dev, d.out_dev, nullptr, nullptr, d.rows, d.cols, dtype, p->block_size, p->mant_bits, p->epsilon,
-                                            N, M, p->sparsify_first, 0, 0, p->exp_win_dev, p->nm_lut_dev, nullptr, own ? (void*)own_stream() : stream);
+                                            N, M, p->sparsify_first, 0, 0, p->exp_win_dev, p->nm_lut_dev, nullptr,
+                                            own ? (void*)lanes.s[lanes.pick(d.rows * d.cols * dtype_size(dtype))] : stream);
             if (rc) return join(rc);
             continue;
         }
@@ -835,7 +870,7 @@ int bfpq_fake_quantize_list(const bfpq_plan* p, const bfpq_tensor_desc* descs, i
 
 int bfpq_fake_quantize_batched(const bfpq_plan* p, const bfpq_tensor_desc* descs, int n, void* stream)
 {
-    return bfpq_fake_quantize_list(p, descs, n, stream, nullptr);
+    return bfpq_fake_quantize_list(p, descs, n, stream, nullptr, 0);
 }
 
 int bfpq_nm_sparsify(const void* in, void* out, int64_t rows, int64_t cols, int dtype, int N, int M,
@@ -894,57 +929,36 @@ int bfpq_prune_quantize(const void* in, void* out, int64_t rows, int64_t cols, i
     return bfpq_quantize_threshold(in, out, nullptr, nullptr, rows, cols, dtype, block_size, mant_bits, epsilon, 0, 0, exp_win, ws, nullptr, stream);
 }
 
-int bfpq_prune_quantize_batched(const bfpq_prune_desc* descs, int n, int dtype, int block_size, int mant_bits, double epsilon,
-                                const uint8_t* exp_win, void* const* wss, int n_ws, void* stream, void* aux_stream)
+// Whole tensors over independent lanes: a tensor's two launches (selection, prune + quantize) go back to back to the lane that has
+// been given the fewest bytes so far, every lane has its own workspace, and nothing orders the lanes against one another.  LLaMA-13B,
+// all 280 weights, bf16 (tools_dev/ab_prune_list.py, hipGraph): one lane 16.8 ms, two 14.2, three 12.7, four 12.5 -- and 15.5 for the
+// round-3 scheme this replaces (selection of tensor i + 1 on the caller's stream beside the apply launch of tensor i on ONE aux
+// stream, ordered by two events per tensor): a lane's serial tail (the last workgroup's resolve step, the kernel boundary) is
+// covered by the other lanes' streaming, and three or four lanes cover it better than one partner does.
+int bfpq_prune_quantize_list(const bfpq_prune_desc* descs, int n, int dtype, int block_size, int mant_bits, double epsilon,
+                             const uint8_t* exp_win, void* const* wss, int n_ws, void* stream, void* const* aux_streams, int n_aux)
 {
-    if (n < 0 || (n > 0 && !descs) || !wss || n_ws < 1) return BFPQ_E_ARG;
+    if (n < 0 || (n > 0 && !descs) || !wss || n_ws < 1 || n_aux < 0 || (n_aux > 0 && !aux_streams)) return BFPQ_E_ARG;
     for (int i = 0; i < n_ws; i++) if (!wss[i]) return BFPQ_E_ARG;
-    hipStream_t sm = (hipStream_t)stream, sa = (hipStream_t)aux_stream;
-    if (!sa || sa == sm || n_ws < 2 || n < 2) {
-        for (int i = 0; i < n; i++) {
-            const int rc = bfpq_prune_quantize(descs[i].in_dev, descs[i].out_dev, descs[i].rows, descs[i].cols, dtype, block_size, mant_bits, epsilon,
-                                               descs[i].k, exp_win, wss[0], stream);
-            if (rc) return rc;
-        }
-        return 0;
-    }
-    constexpr int kMaxWs = 8;
-    const int W = n_ws < kMaxWs ? n_ws : kMaxWs;
-    hipEvent_t fork = nullptr, sel_done[kMaxWs] = {nullptr}, app_done[kMaxWs] = {nullptr};
-    bool app_recorded[kMaxWs] = {false};
+    for (int i = 0; i < n_ws; i++) for (int j = 0; j < i; j++) if (wss[i] == wss[j]) return BFPQ_E_ARG;   // (a workspace per lane)
+    Lanes lanes(stream, aux_streams, n_aux < n_ws - 1 ? n_aux : n_ws - 1);
     int rc = 0;
-    auto hipok = [&](hipError_t e) { if (e != hipSuccess && !rc) rc = (int)e; return e == hipSuccess; };
-    hipok(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-    for (int w = 0; w < W; w++) { hipok(hipEventCreateWithFlags(&sel_done[w], hipEventDisableTiming)); hipok(hipEventCreateWithFlags(&app_done[w], hipEventDisableTiming)); }
-    bool forked = false;
-    if (!rc && hipok(hipEventRecord(fork, sm)) && hipok(hipStreamWaitEvent(sa, fork, 0))) forked = true;
-    int last_aux = -1;
     for (int i = 0; i < n && !rc; i++) {
         const bfpq_prune_desc& d = descs[i];
         if (d.rows < 0 || d.cols < 0 || d.k < 0 || d.k > d.rows * d.cols) { rc = BFPQ_E_ARG; break; }
         if (d.rows * d.cols == 0) continue;
         if (!d.in_dev || !d.out_dev || d.in_dev == d.out_dev) { rc = BFPQ_E_ARG; break; }
-        const int w = i % W;
-        if (app_recorded[w] && !hipok(hipStreamWaitEvent(sm, app_done[w], 0))) break;        // the workspace's previous tensor has been applied
-        rc = bfpq_select(d.in_dev, d.rows * d.cols, dtype, d.k, wss[w], stream);
-        if (rc) break;
-        if (!hipok(hipEventRecord(sel_done[w], sm)) || !hipok(hipStreamWaitEvent(sa, sel_done[w], 0))) break;
-        rc = bfpq_quantize_threshold(d.in_dev, d.out_dev, nullptr, nullptr, d.rows, d.cols, dtype, block_size, mant_bits, epsilon, 0, 0, exp_win, wss[w], nullptr, aux_stream);
-        if (rc) break;
-        if (!hipok(hipEventRecord(app_done[w], sa))) break;
-        app_recorded[w] = true;
-        last_aux = w;
+        const int l = n > 1 ? lanes.pick(d.rows * d.cols * dtype_size(dtype < 0 || dtype > 2 ? 0 : dtype)) : 0;
+        rc = bfpq_prune_quantize(d.in_dev, d.out_dev, d.rows, d.cols, dtype, block_size, mant_bits, epsilon, d.k, exp_win, wss[l], lanes.s[l]);
     }
-    // join: the main stream waits for everything the aux stream was given (also on an error path: a capture must not be left forked)
-    if (forked) {
-        hipEvent_t join = fork;                                   // (re-recorded: its first record has been consumed by the wait above)
-        if (last_aux >= 0 && app_recorded[last_aux]) join = app_done[last_aux];
-        else hipok(hipEventRecord(join, sa));
-        hipok(hipStreamWaitEvent(sm, join, 0));
-    }
-    if (fork) (void)hipEventDestroy(fork);
-    for (int w = 0; w < W; w++) { if (sel_done[w]) (void)hipEventDestroy(sel_done[w]); if (app_done[w]) (void)hipEventDestroy(app_done[w]); }
-    return rc;
+    return lanes.join(rc);
+}
+
+int bfpq_prune_quantize_batched(const bfpq_prune_desc* descs, int n, int dtype, int block_size, int mant_bits, double epsilon,
+                                const uint8_t* exp_win, void* const* wss, int n_ws, void* stream, void* aux_stream)
+{
+    void* aux[1] = {aux_stream};
+    return bfpq_prune_quantize_list(descs, n, dtype, block_size, mant_bits, epsilon, exp_win, wss, n_ws, stream, aux, aux_stream ? 1 : 0);
 }
 
 }  // extern "C"

@@ -76,7 +76,7 @@ def load_library():
         L.bfpq_quantize_nm.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, dbl, i32, i32, i32, i32, u64, vp, vp, vp, vp]
         L.bfpq_fake_quantize.argtypes = [vp, vp, vp, i64, i64, vp]
         L.bfpq_fake_quantize_batched.argtypes = [vp, vp, i32, vp]
-        L.bfpq_fake_quantize_list.argtypes = [vp, vp, i32, vp, vp]
+        L.bfpq_fake_quantize_list.argtypes = [vp, vp, i32, vp, vp, i32]
         L.bfpq_is_fused.argtypes = [i64, i64, i32, i32, i32, i32]
         L.bfpq_nm_sparsify.argtypes = [vp, vp, i64, i64, i32, i32, i32, vp, vp]
         L.bfpq_select_passes.argtypes = [i32]
@@ -85,6 +85,7 @@ def load_library():
         L.bfpq_select.argtypes = [vp, i64, i32, i64, vp, vp]
         L.bfpq_prune_quantize.argtypes = [vp, vp, i64, i64, i32, i32, i32, dbl, i64, vp, vp, vp]
         L.bfpq_prune_quantize_batched.argtypes = [vp, i32, i32, i32, i32, dbl, vp, vp, i32, vp, vp]
+        L.bfpq_prune_quantize_list.argtypes = [vp, i32, i32, i32, i32, dbl, vp, vp, i32, vp, vp, i32]
         L.bfpq_select_hist.argtypes = [vp, i64, i32, i32, i64, i64, vp, vp, vp]
         L.bfpq_select_resolve.argtypes = [vp, i64, i32, i32, i64, vp, i32, i32, vp, vp, vp]
         L.bfpq_threshold_apply.argtypes = [vp, vp, i64, i32, vp, vp]
@@ -106,7 +107,7 @@ def load_library():
         L.bfpq_hbfp_linear_mx8_splitk.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, i64, i32, vp]
         for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_fake_quantize_list", "bfpq_is_fused", "bfpq_nm_sparsify",
                      "bfpq_select_passes", "bfpq_select", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
-                     "bfpq_prune_quantize", "bfpq_prune_quantize_batched",
+                     "bfpq_prune_quantize", "bfpq_prune_quantize_batched", "bfpq_prune_quantize_list",
                      "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize", "bfpq_hbfp_linear_slices",
                      "bfpq_hbfp_linear_decode", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled",
                      "bfpq_mx8_from_hbfp", "bfpq_quantize_mx8", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8",
@@ -119,7 +120,7 @@ def load_library():
 EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_mx8_parts", "bfpq_hbfp_linear_mx8_splitk", "bfpq_quantize_mx8", "bfpq_mx8_from_hbfp", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_select_ws_bytes", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_fake_quantize_list", "bfpq_is_fused", "bfpq_nm_sparsify",
                     "bfpq_select_passes", "bfpq_select", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
-                    "bfpq_prune_quantize", "bfpq_prune_quantize_batched",
+                    "bfpq_prune_quantize", "bfpq_prune_quantize_batched", "bfpq_prune_quantize_list",
                     "bfpq_threshold_apply", "bfpq_quantize_threshold")
 
 
@@ -354,8 +355,9 @@ class FastQuant:
         if k:
             plan = self._plan(dt, dev)
             with torch.cuda.device(dev):
+                aux = aux_stream_array(dev, 1) if k > 1 else None
                 rc = load_library().bfpq_fake_quantize_list(plan[1], ctypes.addressof(descs), k, torch.cuda.current_stream(dev).cuda_stream,
-                                                            aux_stream(dev).cuda_stream if k > 1 else None)
+                                                            ctypes.addressof(aux) if aux is not None else None, 1 if aux is not None else 0)
             if rc:
                 check(rc, "bfpq_fake_quantize_list")
         return res
@@ -402,8 +404,8 @@ class PreparedList:
         self._plan = fq._plan(self.dtype, self.device) if self._k else None
         self._fn = load_library().bfpq_fake_quantize_list
         self._addr = ctypes.addressof(self._descs)
-        # (large tensors of the list get launches of their own, alternating between the current stream and this one)
-        self._aux = aux_stream(self.device).cuda_stream if self._k > 1 else None
+        # (large tensors of the list get launches of their own, spread over the current stream and this one)
+        self._aux = aux_stream_array(self.device, 1) if self._k > 1 else None
 
     def _rebind(self):
         """descriptor j reads self._keep[j]: follow tensors whose storage moved since they were bound"""
@@ -421,12 +423,13 @@ class PreparedList:
         if self._k:
             self._rebind()
             dev = self.device
+            aux, n_aux = (ctypes.addressof(self._aux), len(self._aux)) if self._aux is not None else (None, 0)
             if torch.cuda.current_device() != dev.index:
                 with torch.cuda.device(dev):
-                    rc = self._fn(self._plan[1], self._addr, self._k, torch.cuda.current_stream(dev).cuda_stream, self._aux)
+                    rc = self._fn(self._plan[1], self._addr, self._k, torch.cuda.current_stream(dev).cuda_stream, aux, n_aux)
             else:
                 rc = self._fn(self._plan[1], self._addr, self._k,
-                              _raw_stream(dev.index) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream, self._aux)
+                              _raw_stream(dev.index) if _raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream, aux, n_aux)
             if rc:
                 check(rc, "bfpq_fake_quantize_list")
         return self.outputs
@@ -546,22 +549,31 @@ class _PruneDesc(ctypes.Structure):
 _aux_streams = {}
 
 
-def aux_stream(device):
-    """the side stream (one per device) on which bfpq_prune_quantize_batched runs the apply launches"""
+def aux_streams(device, n=1):
+    """n persistent side streams of the device: the aux lanes of the list calls (bfpq_fake_quantize_list, bfpq_prune_quantize_list)"""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    s = _aux_streams.get(idx)
-    if s is None:
-        s = _aux_streams[idx] = torch.cuda.Stream(torch.device("cuda", idx))
-    return s
+    lst = _aux_streams.setdefault(idx, [])
+    while len(lst) < n:
+        lst.append(torch.cuda.Stream(torch.device("cuda", idx)))
+    return lst[:n]
+
+
+def aux_stream(device):
+    return aux_streams(device, 1)[0]
+
+
+def aux_stream_array(device, n):
+    """the raw handles of aux_streams(device, n) as a C array of void* (the streams themselves live as long as the process)"""
+    return (ctypes.c_void_p * n)(*[s.cuda_stream for s in aux_streams(device, n)])
 
 
 class PruneQuantizeList:
-    """A list of tensors of one dtype on one device bound to the s-first unstructured drop-in op (bfpq_prune_quantize_batched):
-    outputs, descriptors and the workspaces are set up once; run() is ONE ctypes call that pipelines the tensors over the
-    current stream and a side stream (selection of tensor i + 1 beside the prune + quantize pass of tensor i).
+    """A list of tensors of one dtype on one device bound to the s-first unstructured drop-in op (bfpq_prune_quantize_list):
+    outputs, descriptors and the workspaces are set up once; run() is ONE ctypes call that spreads the tensors over N_WS
+    independent lanes (the current stream and side streams, a workspace each; a tensor's two launches stay on its lane).
     ks: elements to prune per tensor, int(numel * frac) as the reference computes it (bfp_ops.py:66)."""
 
-    N_WS = 4
+    N_WS = 4                 # lanes: the current stream + 3 side streams, a workspace each (13B list: 1 lane 16.8 ms, 2: 14.2, 3: 12.7, 4: 12.5)
     GRAPH_FROM = 8           # lists of at least this many tensors replay a hipGraph of the pipeline (captured on the first run)
 
     def __init__(self, tensors, ks, block_size, mant_bits, epsilon, outs=None):
@@ -594,8 +606,8 @@ class PruneQuantizeList:
                 self._ws = [SelectWorkspace(self.device) for _ in range(self.N_WS)]
                 self._ws_ptrs = (ctypes.c_void_p * self.N_WS)(*[w.ws.data_ptr() for w in self._ws])
                 self._win = exp_window_dev(self.dtype, self.device)
-                self._aux = aux_stream(self.device)
-        self._fn = load_library().bfpq_prune_quantize_batched
+                self._aux = aux_stream_array(self.device, self.N_WS - 1)
+        self._fn = load_library().bfpq_prune_quantize_list
         self._graph = None
 
     def _issue(self, pipelined):
@@ -603,9 +615,9 @@ class PruneQuantizeList:
         with torch.cuda.device(dev):
             rc = self._fn(ctypes.addressof(self._descs), self._n, DTYPE_CODE[self.dtype], self.block_size, self.mant_bits, self.epsilon,
                           self._win.data_ptr(), ctypes.addressof(self._ws_ptrs), self.N_WS, torch.cuda.current_stream(dev).cuda_stream,
-                          self._aux.cuda_stream if pipelined else None)
+                          ctypes.addressof(self._aux) if pipelined else None, len(self._aux) if pipelined else 0)
         if rc:
-            check(rc, "bfpq_prune_quantize_batched")
+            check(rc, "bfpq_prune_quantize_list")
 
     def run(self, pipelined=True, graph=None):
         """graph: replay a hipGraph of the whole pipeline (captured on the first such run; every pointer in it is bound --

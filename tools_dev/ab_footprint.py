@@ -24,29 +24,30 @@ def timed(fn, per):
     return statistics.median(ts)
 
 
-side = torch.cuda.Stream(device=dev)
+sides = [torch.cuda.Stream(device=dev) for _ in range(3)]
 for rows, cols in ((4096, 11008), (4096, 4096), (1024, 4096)):
     for R in (8, 64):
         g = torch.Generator(device=dev).manual_seed(7)
         ins = [(torch.randn(rows, cols, generator=g, device=dev) * 0.02).to(torch.bfloat16) for _ in range(R)]
         outs = [torch.empty_like(x) for x in ins]
 
-        def flat():
-            for i in range(L):
-                fq(ins[i % R], out=outs[i % R])
-
-        def flat2():
-            main = torch.cuda.current_stream()
-            side.wait_stream(main)
-            for i in range(L):
-                if i & 1:
-                    with torch.cuda.stream(side):
+        def lanes(S):
+            def f():
+                main = torch.cuda.current_stream()
+                for s in sides[:S - 1]:
+                    s.wait_stream(main)
+                for i in range(L):
+                    if i % S:
+                        with torch.cuda.stream(sides[i % S - 1]):
+                            fq(ins[i % R], out=outs[i % R])
+                    else:
                         fq(ins[i % R], out=outs[i % R])
-                else:
-                    fq(ins[i % R], out=outs[i % R])
-            main.wait_stream(side)
+                for s in sides[:S - 1]:
+                    main.wait_stream(s)
+            return f
         res = []
-        for f in (flat, flat2):
+        for S in (1, 2, 3, 4):
+            f = lanes(S)
             f(); torch.cuda.synchronize()
             gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr):
@@ -54,8 +55,9 @@ for rows, cols in ((4096, 11008), (4096, 4096), (1024, 4096)):
             res.append(timed(gr.replay, L))
             del gr
         pl = native.PreparedList(fq, [ins[i % R] for i in range(L)], outs=[outs[i % R] for i in range(L)])
+        pl._aux = None
         t_list = timed(pl.run, L)
-        print(f"[{rows},{cols}] R = {R:3d} pairs ({R * rows * cols * 4 / 1e9:5.1f} GB): one launch per tensor {res[0]:6.2f} us, "
-              f"the same over two streams {res[1]:6.2f} us, list kernel {t_list:6.2f} us / tensor", flush=True)
+        print(f"[{rows},{cols}] R = {R:3d} pairs ({R * rows * cols * 4 / 1e9:5.1f} GB): one launch per tensor over 1 / 2 / 3 / 4 streams "
+              f"{res[0]:6.2f} / {res[1]:6.2f} / {res[2]:6.2f} / {res[3]:6.2f} us, the list call on one stream {t_list:6.2f} us / tensor", flush=True)
         del ins, outs, pl
         torch.cuda.empty_cache()

@@ -57,3 +57,28 @@ for name, pipe in (("serial hipGraph", False), ("pipelined hipGraph", True)):
         pl.run(pipelined=pipe, graph=False)
     us = timed(gr.replay)
     print(f"{name:24s} {us/1e3:8.2f} ms  {numel*4/us/1e3:7.0f} GB/s on 4 B/elem ({numel*4/us/80e3:5.1f} %)  {numel*6/us/80e3:5.1f} % on the two-read 6 B/elem", flush=True)
+
+# whole tensors alternating over S independent streams (each tensor's two launches back to back on its stream, a workspace per
+# stream): no events between the streams except the fork and the join
+for S in (2, 3, 4):
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    wss = [native.SelectWorkspace(dev) for _ in range(S)]
+    outs_all = prep.run()
+    torch.cuda.synchronize()
+
+    def indep():
+        main = torch.cuda.current_stream()
+        for s in streams:
+            s.wait_stream(main)
+        for i, w in enumerate(ws):
+            with torch.cuda.stream(streams[i % S]):
+                native.prune_quantize(w, w.numel() // 2, wss[i % S], 64, 3, 1e-8, out=outs_all[i])
+        for s in streams:
+            main.wait_stream(s)
+    indep(); torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        indep()
+    us = timed(gr.replay)
+    print(f"{S} independent streams, hipGraph {us/1e3:8.2f} ms  {numel*4/us/1e3:7.0f} GB/s on 4 B/elem ({numel*4/us/80e3:5.1f} %)  {numel*6/us/80e3:5.1f} % on the two-read 6 B/elem", flush=True)
+    del gr
