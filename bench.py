@@ -276,6 +276,53 @@ def main():
                                           "what": f"[5120,5120] {args.dtype}: global 50 % magnitude pruning then HBFP4 block 64 (first='s'), selection launch + fused "
                                                   "prune+quantize launch; two-read figure = 6 B/element (the tensor is read by both launches), single-read = 4 B/element"}
             del u_ins, u_outs
+            # (3) the same launches spread over two lanes (the caller's stream and one side stream: bfpq_fake_quantize_list): what a pass
+            #     over many tensors gets per tensor, the tail of one launch running beside the ramp of the next
+            fq = native.FastQuant(args.block, args.mant_bits, 1e-8, N, M, args.first == "s")
+            reps = 64
+            pl = native.PreparedList(fq, [ins[i % R] for i in range(reps)], outs=[outs[i % R] for i in range(reps)])
+            rounds = max(1, short // reps)
+            _, l_ms = timed_loop(lambda i: pl.run(), rounds, 1, True)
+            l_us = l_ms * 1e3 / (rounds * reps)
+            extra["two_lanes"] = {"us_per_tensor": l_us, "elems/s": numel / l_us * 1e6, "GB/s": 2 * numel * esize / l_us / 1e3,
+                                  "frac": 2 * numel * esize / l_us / 1e3 / HBM_PEAK_GBPS, "launch": "hipGraph", "tensors_per_list_call": reps,
+                                  "what": "the headline launches as ONE list call per 64 tensors (same rotating buffers): every tensor still gets its own "
+                                          "k_fused_flat launch, alternating between the caller's stream and a side stream; two launches share the chip, so "
+                                          "this is a throughput figure, not a per-launch duration"}
+            del pl
+            # (4) BASELINE configs 3 and 4 whole: every Linear weight of LLaMA-7B (2:4 -> HBFP4) and of LLaMA-13B (50 % unstructured -> HBFP4)
+            #     through one prepared list call each (weights drawn on the device, randn * 0.02; outputs bound once)
+            def model_pass(shapes, kw, bytes_per_elem):
+                gd = torch.Generator(device=dev).manual_seed(1234)
+                wl = [(torch.randn(r, c, generator=gd, device=dev) * 0.02).to(dtype) for r, c in shapes]
+                prep = bfp_ops.PreparedMany(wl, identifier='w', **kw)
+                prep.run(); prep.run()
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(5):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); prep.run(); e1.record(); torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                ms = sorted(ts)[len(ts) // 2]
+                n = sum(w.numel() for w in wl)
+                del prep, wl
+                torch.cuda.empty_cache()
+                return {"ms_per_pass": ms, "tensors": len(shapes), "elems": n, "elems/s": n / ms * 1e3,
+                        "frac": n * bytes_per_elem / ms / 1e6 / HBM_PEAK_GBPS, "bytes_per_elem": bytes_per_elem}
+
+            def llama(h, inter, layers):
+                return [(h, h)] * 4 * layers + [(inter, h)] * 2 * layers + [(h, inter)] * layers
+            try:
+                c3 = pkg.BFPConfig.hbfp(args.mant_bits + 1, args.block, w_sparsity=True, N=N, M=M, sparsity_mode='structured', first=args.first).to_kwargs()
+                extra["model_pass_cfg3"] = dict(model_pass(llama(4096, 11008, 32), c3, 2 * esize),
+                                                what=f"LLaMA-7B, all 224 Linear weights {args.dtype}: {args.nm} -> HBFP{args.mant_bits + 1} block {args.block}, one prepared "
+                                                     "list call (bfpq_fake_quantize_list, two lanes), HIP events around the eager call, median of 5")
+                extra["model_pass_cfg4"] = dict(model_pass(llama(5120, 13824, 40), c4, 3 * esize),
+                                                what=f"LLaMA-13B, all 280 Linear weights {args.dtype}: 50 % unstructured -> HBFP{args.mant_bits + 1} block {args.block}, one "
+                                                     "prepared list call (bfpq_prune_quantize_list, four lanes, its own hipGraph); frac on the two-read "
+                                                     "figure (6 B per element: the selection and the prune + quantize launch both read the tensor)")
+            except Exception as e:                                  # (never at the cost of the main line)
+                extra["model_pass_error"] = f"{type(e).__name__}: {e}"
         value = world * numel * args.steps / wall
         kern_us = ev_ms * 1e3 / args.steps
         bytes_per_launch = numel * esize + (numel * esize if want_deq else 0) + (numel * code_bits // 8 if code_bits else 0) + \

@@ -801,7 +801,8 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
     // entry edge both edges need vmcnt(1) and the store stays in flight across the loop top (A/B: 32.5 -> 31.95 us).
     // NB the scheduler still hoists the tile's first v_perm above the next prefetch, so a wave has ONE load in flight,
     // issued when the previous arrives; pinning the prefetch in front of that wait (two loads in flight) measured
-    // SLOWER (33.25 us) -- like every other variant with more reads in flight per wave on this part.
+    // SLOWER (33.25 us) -- like every other variant with more reads in flight per wave on this part.  (r03: also the second tile's
+    // load issued once, in front of the table set-up, to fill the ramp of the launch: 31.90 against 31.54 us interleaved.)
     asm volatile("" ::: "memory");                                         // (pins the dummy between the first load and the loop)
     const uint32_t dummy = *reinterpret_cast<const uint32_t*>(src);
     asm volatile("" ::: "memory");
