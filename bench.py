@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--weak", action="store_true", help="N > 1: every rank its own [rows, cols] slab, no collective")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the sub-records (packed, cfg4, two_lanes, model passes): for profiler runs, "
+                                                                 "so that the kernel statistics hold the timed region's launches only")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) for real multi-GPU; gloo only to rehearse N>1 on one GPU")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -234,7 +236,7 @@ def main():
         use_graph = not args.eager and args.mode == "dropin"
         wall, ev_ms = timed_loop(step, args.steps, args.warmup, use_graph)
         wall = max_over_ranks(wall)
-        if world == 1 and args.mode == "dropin" and not args.eager and args.block == 64 and pack_bits == 4 and esize == 2:
+        if world == 1 and args.mode == "dropin" and not args.eager and args.block == 64 and pack_bits == 4 and esize == 2 and not args.headline_only:
             # ---- two more measurements of the same call path on the same rotating inputs (sub-records of the line) ----------
             # (1) north_star's "packed int4 stores": the kernel writes 4-bit codes + int8 exponents and no dequantised tensor
             short = max(40, args.steps // 4)
