@@ -174,8 +174,10 @@ def main():
                                   want_deq=not packed, code_bits=pack_bits if packed else 0, want_exp=packed,
                                   out=out, codes_out=codes_out, exps_out=exps_out)
 
-    def timed_loop(fn, steps, warmup, graph):
-        """(wall seconds, HIP-event milliseconds) of `steps` calls of fn(i), barrier + synchronize on both sides"""
+    def timed_loop(fn, steps, warmup, graph, repeats=1):
+        """(wall seconds, HIP-event milliseconds) of `steps` calls of fn(i), barrier + synchronize on both sides.
+        repeats > 1 (sub-records only, hipGraph): the median of that many timed replays -- a single replay of a few
+        milliseconds right after an idle gap is also a measurement of the clocks coming back up."""
         for i in range(warmup):
             fn(i)
         sync_all()
@@ -187,6 +189,17 @@ def main():
                     fn(i)
             g.replay()                                              # untimed: upload + first replay
             sync_all()
+            if repeats > 1:
+                walls, evs = [], []
+                for _ in range(repeats):
+                    t0 = time.perf_counter()
+                    ev0.record()
+                    g.replay()
+                    ev1.record()
+                    sync_all()
+                    walls.append(time.perf_counter() - t0)
+                    evs.append(ev0.elapsed_time(ev1))
+                return sorted(walls)[repeats // 2], sorted(evs)[repeats // 2]
             t0 = time.perf_counter()
             ev0.record()
             g.replay()
@@ -247,11 +260,11 @@ def main():
                 r = i % R
                 return native.quantize_nm(ins[r], args.block, args.mant_bits, 1e-8, N=N, M=M, sparsify_first=(args.first == "s"),
                                           want_deq=False, code_bits=4, want_exp=True, codes_out=pcs[r], exps_out=pes[r])
-            _, p_ms = timed_loop(packed_step, short, 10, True)
+            _, p_ms = timed_loop(packed_step, short, 10, True, repeats=5)
             p_us = p_ms * 1e3 / short
             p_bytes = numel * esize + numel // 2 + numel // args.block
             extra["packed"] = {"us": p_us, "GB/s": p_bytes / p_us / 1e3, "frac": p_bytes / p_us / 1e3 / HBM_PEAK_GBPS,
-                               "algorithmic_bytes_per_launch": p_bytes, "launch": "hipGraph", "rotating_buffers": R,
+                               "algorithmic_bytes_per_launch": p_bytes, "launch": "hipGraph, median of 5 replays", "rotating_buffers": R,
                                "what": "same inputs, same 2:4 -> HBFP4 arithmetic; output = 4-bit two's-complement codes + one int8 shared exponent "
                                        "per block of 64 (2 + 0.5 + 1/64 B per element), k_fused_flat<.., PACK = 4>"}
             del pcs, pes
@@ -269,7 +282,7 @@ def main():
             def unstructured_step(i):
                 r = i % R
                 return native.prune_quantize(u_ins[r], u_ins[r].numel() // 2, ws, args.block, args.mant_bits, 1e-8, out=u_outs[r])
-            _, u_ms = timed_loop(unstructured_step, short, 10, True)
+            _, u_ms = timed_loop(unstructured_step, short, 10, True, repeats=5)
             u_us = u_ms * 1e3 / short
             un = 5120 * 5120
             extra["cfg4_unstructured"] = {"us": u_us, "elems/s": un / u_us * 1e6,
@@ -284,7 +297,7 @@ def main():
             reps = 64
             pl = native.PreparedList(fq, [ins[i % R] for i in range(reps)], outs=[outs[i % R] for i in range(reps)])
             rounds = max(1, short // reps)
-            _, l_ms = timed_loop(lambda i: pl.run(), rounds, 1, True)
+            _, l_ms = timed_loop(lambda i: pl.run(), rounds, 1, True, repeats=5)
             l_us = l_ms * 1e3 / (rounds * reps)
             extra["two_lanes"] = {"us_per_tensor": l_us, "elems/s": numel / l_us * 1e6, "GB/s": 2 * numel * esize / l_us / 1e3,
                                   "frac": 2 * numel * esize / l_us / 1e3 / HBM_PEAK_GBPS, "launch": "hipGraph", "tensors_per_list_call": reps,
