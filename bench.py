@@ -419,6 +419,19 @@ def main():
         extra["overlapped"] = {"value": numel * short / owall, "unit": "elems/s", "ms_per_step": owall * 1e3 / short, "chunks": 4,
                                "what": "dist.gather_overlapped: the slab in 4 row chunks, chunk i's all_gather_into_tensor (persistent side stream, "
                                        "contiguous staging buffer + one strided copy) beside the kernel of chunk i + 1"}
+        # every rank a whole [rows, cols] tensor of its own, no collective (the --weak form, here as a sub-record: rows are
+        # independent units, so this is what the path does when the caller does NOT need the tensor whole on every rank)
+        w_ins = [f.to(dev) for f in fulls[:min(R, 4)]]
+        w_outs = [torch.empty_like(x) for x in w_ins]
+
+        def weak_step(i):
+            quantize(w_ins[i % len(w_ins)], out=w_outs[i % len(w_ins)])
+        wwall, _ = timed_loop(weak_step, short, 5, False)
+        wwall = max_over_ranks(wwall)
+        extra["weak_no_collective"] = {"value": world * numel * short / wwall, "unit": "elems/s", "ms_per_step": wwall * 1e3 / short,
+                                       "what": f"every rank quantizes its own whole [{args.rows},{args.cols}] tensor, no collective "
+                                               "(per-GPU work fixed: weak scaling of the path itself), eager"}
+        del w_ins, w_outs
         _, k_ms = timed_loop(kernel_only, short, 5, False)
         _, c_ms = timed_loop(gather_only, short, 5, False)
         _, pcoll_ms = timed_loop(packed_gather_only, short, 5, False)
