@@ -125,8 +125,9 @@ int bfpq_fake_quantize_batched(const bfpq_plan* plan_host, const bfpq_tensor_des
  * tensor's launch runs beside the ramp of another's (64 x [4096,11008] bf16 2:4 -> HBFP4, us per tensor: one aux stream 29.5-30.2,
  * none 31.9-33.4, the list kernel 35.7-37.0; LLaMA-7B's 224 weights 4.07 ms against 5.31; more than one aux stream buys nothing here).
  * The aux lanes wait for what `stream` held at the call and `stream` waits for them before the call returns (one fork, one join, no
- * event between the lanes: hipGraph-capturable from `stream`).  The tensors of one list must not overlap one another (they are
- * processed side by side).  bfpq_fake_quantize_batched(...) is bfpq_fake_quantize_list(..., stream, NULL, 0). */
+ * event between the lanes: hipGraph-capturable from `stream`).  A list with fewer than two such tensors stays on `stream` (a Linear's
+ * weight next to its activation: the fork and join would cost more than they gain).  The tensors of one list must not overlap one
+ * another (they are processed side by side).  bfpq_fake_quantize_batched(...) is bfpq_fake_quantize_list(..., stream, NULL, 0). */
 int bfpq_fake_quantize_list(const bfpq_plan* plan_host, const bfpq_tensor_desc* descs_host, int n, void* stream,
                             void* const* aux_streams_host, int n_aux);
 

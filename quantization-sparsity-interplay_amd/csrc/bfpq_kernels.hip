@@ -831,6 +831,15 @@ int bfpq_fake_quantize_list(const bfpq_plan* p, const bfpq_tensor_desc* descs, i
     // (the small tensors' list launches stay on the caller's stream: spread over the lanes in byte-budgeted batches they were SLOWER --
     // OPT-125m's 72 weights 147 us against 122-131, ViT-L's 144 weights 462 against 417-439: the fork and the join cost more than two
     // concurrent list launches gain)
+    // lanes only pay when at least two tensors get launches of their own: for ONE large tensor next to small ones (a Linear's weight
+    // next to its activation) the fork and the join cost more than running the two side by side gains (bench_linear.py, un-cached
+    // BFPLinear forward, 16 tokens x down_proj: 75.2 us with the weight on an aux lane against 72.6 on one stream)
+    if (lanes.n > 1) {
+        int n_own = 0;
+        for (int i = 0; i < n; i++)
+            if (descs[i].rows > 0 && descs[i].cols > 0 && descs[i].rows * descs[i].cols * dtype_size(dtype) >= kListOwnLaunchBytes) n_own++;
+        if (n_own < 2) lanes.n = 1;
+    }
     auto flush = [&]() -> int {
         if (b.n == 0) return 0;
         const int M = batch_has_nm ? 4 : 0;
