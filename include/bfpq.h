@@ -48,6 +48,7 @@ int bfpq_version(void);
 /* process-wide tuning knobs (measurement aid; defaults are the measured optimum on MI355X) */
 #define BFPQ_TUNE_MAX_GRID 0       /* cap on workgroups of the streaming kernels (default 1024) */
 #define BFPQ_TUNE_GEMM_ROW_TILES 1 /* 16-row tiles per wave in bfpq_hbfp_linear_decode_tiled: 0 = choose (default), 1, 2, 4 */
+#define BFPQ_TUNE_LIST_OWN_MB 3    /* list calls: tensors from this many MB on get launches of their own (default 24; 0 = all, a huge value = none) */
 #define BFPQ_TUNE_MX8_VARIANT 2    /* tile shape of bfpq_hbfp_linear_mx8: -1 = choose (default), 0..6 force (A/B measurements) */
 int bfpq_tune(int key, int value);
 const char* bfpq_error_string(int code);

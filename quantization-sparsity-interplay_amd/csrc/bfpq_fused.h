@@ -645,6 +645,8 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
             }
         }
         __syncthreads();
+        // (the flat sweep's loop-top trick -- one more memory operation behind the first load, so that the loop-top wait leaves the previous
+        // store in flight -- measured SLOWER here: ViT-L's 144 weights 434 against 417 us, 64 x [4096,11008] 2238 against 2113, tools_dev/ab_list.py)
         // two chunks per trip, register sets alternating by name (as the flat sweep below), bodies unguarded
         for (; cc < total && cc + G < total; cc += 2 * G) {
             const Cur cB = locate(cc + G);

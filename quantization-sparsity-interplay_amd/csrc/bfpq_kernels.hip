@@ -31,6 +31,7 @@ extern "C" __attribute__((visibility("hidden"))) int bfpq_g_mx8_variant;   // bf
 #include "bfpq_quant_math.h"
 
 extern "C" { __attribute__((visibility("hidden"))) int bfpq_g_max_grid = BFPQ_MAXGRID; }
+static int bfpq_g_list_own_mb = 24;     // bfpq_tune(BFPQ_TUNE_LIST_OWN_MB): tensors of a list call from this many MB on get launches of their own
 
 
 using namespace bfpq_dev;
@@ -549,6 +550,7 @@ int bfpq_tune(int key, int value)
     if (key == BFPQ_TUNE_MAX_GRID && value >= 1 && value <= 65535) { bfpq_g_max_grid = value; return 0; }
     if (key == BFPQ_TUNE_GEMM_ROW_TILES && (value == 0 || value == 1 || value == 2 || value == 4)) { bfpq_g_gemm_rt = value; return 0; }
     if (key == BFPQ_TUNE_MX8_VARIANT && value >= -1 && value <= 6) { bfpq_g_mx8_variant = value; return 0; }
+    if (key == BFPQ_TUNE_LIST_OWN_MB && value >= 0) { bfpq_g_list_own_mb = value; return 0; }
     return BFPQ_E_ARG;
 }
 
@@ -748,7 +750,7 @@ int bfpq_fake_quantize(const bfpq_plan* p, const void* in, void* out, int64_t ro
 // 5.4-5.5.  The list kernel's workgroups drift apart over a long list (no launch boundary pulls the sweep's front together again)
 // and it wins only where a launch of its own would be mostly ramp and tail; two streams let the tail of one tensor's launch run
 // beside the ramp of the next one.
-constexpr int64_t kListOwnLaunchBytes = (int64_t)24 << 20;
+#define kListOwnLaunchBytes ((int64_t)bfpq_g_list_own_mb << 20)
 
 // Lanes of a list call: the caller's stream (lane 0) and up to kMaxLanes - 1 aux streams.  Every tensor that gets launches of its
 // own goes, whole, to the lane that has been given the fewest bytes so far; the lanes run side by side without any event between
