@@ -109,9 +109,12 @@ def main():
     ap.add_argument("--models", action="store_true", help="also (or with --models-only: only) the whole-model passes")
     ap.add_argument("--models-only", action="store_true")
     ap.add_argument("--eager", action="store_true", help="no hipGraph (counter collection: every dispatch is its own record)")
+    ap.add_argument("--no-list-graph", action="store_true", help="whole-model rows: the unstructured list issues its launches eagerly (kernel traces: the profiler serialises the nodes of a replayed graph)")
     ap.add_argument("--tune-grid", type=int, default=0, help="A/B: cap on workgroups of the streaming kernels (bfpq_tune key 0)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    if args.no_list_graph:
+        native.PruneQuantizeList.GRAPH_FROM = 1 << 30
     if args.tune_grid:
         assert native.load_library().bfpq_tune(0, args.tune_grid) == 0
     results = []
