@@ -432,6 +432,23 @@ def main():
                                        "what": f"every rank quantizes its own whole [{args.rows},{args.cols}] tensor, no collective "
                                                "(per-GPU work fixed: weak scaling of the path itself), eager"}
         del w_ins, w_outs
+        # BASELINE config 4 as specified, at a reduced list: 16 LLaMA-13B q_proj weights [5120,5120], 50 % unstructured -> HBFP4, every rank
+        # its row slab of every weight; one histogram all-gather per tensor.  lanes = 1: tensor after tensor; lanes = 4: dealt to
+        # four streams, one tensor's exchange beside the others' kernels (dist.float_to_bfp_blocked_many_sharded)
+        if 5120 % world == 0 and esize == 2:
+            gq = torch.Generator(device=dev).manual_seed(4321)
+            q_slabs = [(torch.randn(5120 // world, 5120, generator=gq, device=dev) * 0.02).to(dtype) for _ in range(16)]
+            c4 = pkg.BFPConfig.hbfp(args.mant_bits + 1, args.block, w_sparsity=True, sparsity_mode='unstructured', sparsity_frac=0.5, first='s').to_kwargs()
+            rec = {"tensors": 16, "shape": [5120, 5120], "what": "16 x [5120,5120] row-sharded, 50 % unstructured -> HBFP4 (first = 's'), no result gather: "
+                                                                   "selection launch, histogram all-gather, resolve launch, prune + quantize launch per tensor"}
+            for ln in (1, 4):
+                def list_step(i, ln=ln):
+                    qd.float_to_bfp_blocked_many_sharded(q_slabs, [5120] * 16, identifier='w', lanes=ln, **c4)
+                lwall, _ = timed_loop(list_step, 5, 2, False)
+                rec[f"ms_per_pass_lanes{ln}"] = max_over_ranks(lwall) * 1e3 / 5
+            rec["elems/s_lanes4"] = 16 * 5120 * 5120 / rec["ms_per_pass_lanes4"] * 1e3
+            extra["cfg4_sharded_list"] = rec
+            del q_slabs
         _, k_ms = timed_loop(kernel_only, short, 5, False)
         _, c_ms = timed_loop(gather_only, short, 5, False)
         _, pcoll_ms = timed_loop(packed_gather_only, short, 5, False)

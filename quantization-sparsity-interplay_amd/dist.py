@@ -145,6 +145,48 @@ def float_to_bfp_blocked_sharded(local, rows_total, group=None, gather=False, co
     return all_gather_rows(out, rows_total, group) if gather else out
 
 
+def float_to_bfp_blocked_many_sharded(locals_, rows_totals, group=None, gather=False, identifier='', lanes=4, compute=None, engine=None,
+                                      **bfp_args):
+    """float_to_bfp_blocked_sharded for a LIST of row-sharded tensors -- every Linear weight of a model, each rank holding its
+    row slab of every weight (BASELINE config 4 as specified: LLaMA-13B, 50 % unstructured, row-sharded).
+    Structured / dense configurations have no exchange: the slabs go through one list call (bfp_ops.float_to_bfp_blocked_many:
+    large slabs in launches of their own over two streams), then the optional all-gathers.
+    Unstructured pruning has one histogram all-gather per tensor (three for fp32) between its launches; issued tensor after
+    tensor on one stream, every exchange would leave the device idle for its whole latency.  Here the tensors are dealt
+    round-robin to `lanes` streams (the current one and side streams, each with its own select workspace), so that the
+    exchange of one tensor runs beside the kernels of the others; the collectives are still ISSUED in list order on every
+    rank, which is all a communicator needs.  Results are byte-identical to the per-tensor call.
+    compute / engine: as in float_to_bfp_blocked_sharded (CPU rehearsal of the protocol with stand-ins: tensor after tensor)."""
+    locals_ = list(locals_)
+    n = len(locals_)
+    assert len(rows_totals) == n
+    sparsity = bfp_ops._select_sparsity(bfp_args.get('in_sparsity'), bfp_args.get('w_sparsity'),
+                                        bfp_args.get('grad_sparsity'), identifier)
+    unstructured = bool(sparsity) and bfp_args.get('sparsity_mode') == 'unstructured'
+    on_gpu = n > 0 and all(t.device.type == "cuda" for t in locals_)
+    if not unstructured and on_gpu and compute is None:
+        outs = bfp_ops.float_to_bfp_blocked_many(locals_, identifier=identifier, **bfp_args)
+        return [all_gather_rows(o, r, group) for o, r in zip(outs, rows_totals)] if gather else outs
+    if not on_gpu or lanes <= 1 or n < 2:
+        return [float_to_bfp_blocked_sharded(t, r, group, gather, compute, engine, identifier=identifier, **bfp_args)
+                for t, r in zip(locals_, rows_totals)]
+    dev = locals_[0].device
+    main = torch.cuda.current_stream(dev)
+    streams = [main] + native.aux_streams(dev, min(lanes, n) - 1)
+    for s in streams[1:]:
+        s.wait_stream(main)
+    outs = [None] * n
+    for i, (t, r) in enumerate(zip(locals_, rows_totals)):
+        s = streams[i % len(streams)]
+        with torch.cuda.stream(s):
+            outs[i] = float_to_bfp_blocked_sharded(t, r, group, gather, compute, engine, identifier=identifier, **bfp_args)
+            if s is not main:
+                outs[i].record_stream(main)                        # (allocated on a side stream, consumed on the caller's)
+    for s in streams[1:]:
+        main.wait_stream(s)
+    return outs
+
+
 def float_to_bfp_packed_sharded(local, rows_total, mant_bits, block_size, group=None, gather=False, **kw):
     """packed codes + exponents of this rank's slab; gather=True all-gathers both (the cheap wire format)"""
     codes, exps = bfp_ops.float_to_bfp_packed(local, mant_bits, block_size, **kw)

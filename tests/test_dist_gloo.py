@@ -122,6 +122,16 @@ def _worker(rank, world, port, tmpdir):
                     assert int((allp == 0).sum()) == int((ref == 0).sum())
                     assert torch.equal(allp.float().abs().min(dim=1)[0] >= 0, torch.ones(rows, dtype=torch.bool))
             results[rows] = True
+        # the list form (on CPU: tensor after tensor, same collectives in the same order on every rank)
+        fulls = [(torch.randn(r, 256, generator=g) * 0.02).to(torch.bfloat16) for r in (64, 37, 5)]
+        slabs = [qd.shard_rows(f, world, rank) for f in fulls]
+        cu = _cfg(sparsity_mode='unstructured', sparsity_frac=0.5)
+        many = qd.float_to_bfp_blocked_many_sharded(slabs, [f.shape[0] for f in fulls], gather=True, compute=O.float_to_bfp_blocked, engine=NumpyEngine(),
+                                                    identifier='w', **cu)
+        for f, m in zip(fulls, many):
+            one = qd.float_to_bfp_blocked_sharded(qd.shard_rows(f, world, rank), f.shape[0], gather=True, compute=O.float_to_bfp_blocked, engine=NumpyEngine(),
+                                                  identifier='w', **cu)
+            assert torch.equal(m.view(torch.int16), one.view(torch.int16))
         # chunked gather (overlap path; on CPU the chunks simply run in order)
         full = (torch.randn(64, 256, generator=g) * 0.02).to(torch.bfloat16)
         c = _cfg()

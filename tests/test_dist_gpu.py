@@ -90,6 +90,21 @@ def _worker(rank, world, port, backend, one_device, tmpdir):
         got = qd.float_to_bfp_blocked_sharded(local, 5120, gather=True, identifier='w', **cu)
         assert torch.equal(bits(got), bits(single)), "cfg4 [5120,5120] sharded"
         assert int((got == 0).sum()) >= full.numel() // 2
+        # the list form (every weight of a model, each rank its slabs): tensors dealt to streams so that one tensor's histogram
+        # exchange runs beside the others' kernels -- same bytes as the per-tensor calls, structured and unstructured, bf16 and fp32
+        for dt in (torch.bfloat16, torch.float32):
+            gl = torch.Generator(device=dev).manual_seed(21)
+            fulls = [(torch.randn(r, k, generator=gl, device=dev) * 0.02).to(dt) for r, k in ((512, 1024), (37, 512), (1024, 2048), (3, 256), (768, 768))]
+            slabs = [qd.shard_rows(f, world, rank) for f in fulls]
+            rts = [f.shape[0] for f in fulls]
+            for cl in (_cfg(sparsity_mode='unstructured', sparsity_frac=0.5, first='s'), _cfg(sparsity_mode='unstructured', sparsity_frac=0.3, first='q'), _cfg()):
+                want = [bfp_ops.float_to_bfp_blocked(f, **cl, identifier='w') for f in fulls]
+                got = qd.float_to_bfp_blocked_many_sharded(slabs, rts, gather=True, identifier='w', lanes=3, **cl)
+                for i, (a, b) in enumerate(zip(got, want)):
+                    assert torch.equal(bits(a), bits(b)), ("list form", dt, cl['sparsity_mode'], cl['first'], i)
+                parts = qd.float_to_bfp_blocked_many_sharded(slabs, rts, gather=False, identifier='w', lanes=2, **cl)
+                for i, (a, b) in enumerate(zip(parts, want)):
+                    assert torch.equal(bits(a), bits(qd.shard_rows(b, world, rank))), ("list form, slabs", dt, cl['sparsity_mode'], i)
         # the overlapped gather (persistent side stream, staging buffer + strided copy) == the plain gather
         if 5120 % world == 0:
             c = _cfg()
