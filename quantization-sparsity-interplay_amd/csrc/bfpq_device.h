@@ -131,7 +131,10 @@ struct FusedArgs {
 // items cut into chunks of 256 (the last chunk of a tensor is ragged), the chunks of all tensors form one index space
 // that the workgroups stride over.  flags bit 0: apply the N:M mask to this tensor (a Linear's weight) or not (its activation).
 constexpr int kCodeBitsE4M3 = 108;                 // FusedArgs.code_bits: e4m3 image bytes + E8M0 scales (internal: bfpq_quantize_mx8 on fp32 tensors)
-constexpr int kMaxBatch = 64;
+#ifndef BFPQ_MAX_BATCH
+#define BFPQ_MAX_BATCH 64          // (A/B, tools_dev/ab_list.py, one box: ViT-L's 144 weights 16 / 32 / 64 / 112 per launch = 419 / 409 / 405-425 / 451 us,
+#endif                             //  OPT-125m's 72 weights 128 / 121 / 117-122 / 122 us: longer launches drift apart, shorter ones pay their ramps)
+constexpr int kMaxBatch = BFPQ_MAX_BATCH;
 struct BatchDesc { const void* in; void* out; int64_t n_items; uint32_t chunk0; uint32_t flags; };
 struct BatchArgs { int n; uint32_t total_chunks; BatchDesc d[kMaxBatch]; };
 
