@@ -36,6 +36,20 @@ def test_argument_validation_without_gpu():
     assert L.bfpq_threshold_apply(one, one, 0, native.BF16, one, n) == 0                                                # empty: no launch
     assert L.bfpq_int_quantize(one, one, 1, 4, 4, 5, 8, n, n) == -1
     assert L.bfpq_tune(0, 0) == -1 and L.bfpq_tune(99, 5) == -1 and L.bfpq_tune(0, 1280) == 0
+    assert L.bfpq_tune(3, -1) == -1 and L.bfpq_tune(3, 24) == 0                                                        # own-launch threshold of list calls
+    # list entry points (ABI 4): rejected before anything is launched or any event is made
+    plan = native._Plan(native.BF16, 64, 3, 2, 4, 1, 1e-8, 16, 16)
+    pp = ctypes.c_void_p(ctypes.addressof(plan))
+    assert L.bfpq_fake_quantize_list(n, one, 1, n, n, 0) == -1                                                          # no plan
+    assert L.bfpq_fake_quantize_list(pp, n, 1, n, n, 0) == -1                                                           # descriptors missing
+    assert L.bfpq_fake_quantize_list(pp, one, 1, n, n, 2) == -1                                                         # aux count without aux streams
+    assert L.bfpq_fake_quantize_list(pp, one, 0, n, n, 0) == 0 and L.bfpq_fake_quantize_batched(pp, one, 0, n) == 0     # empty list: ok
+    bad = native._TensorDesc(16, 16, -1, 64, 1, 0)
+    assert L.bfpq_fake_quantize_list(pp, ctypes.c_void_p(ctypes.addressof(bad)), 1, n, n, 0) == -1                      # negative rows
+    wsp = (ctypes.c_void_p * 2)(16, 16)
+    assert L.bfpq_prune_quantize_list(one, 1, native.BF16, 64, 3, 1e-8, one, ctypes.c_void_p(ctypes.addressof(wsp)), 2, n, n, 0) == -1   # one workspace given twice
+    assert L.bfpq_prune_quantize_list(one, 1, native.BF16, 64, 3, 1e-8, one, n, 1, n, n, 0) == -1                       # no workspaces
+    assert L.bfpq_prune_quantize_list(n, 0, native.BF16, 64, 3, 1e-8, one, ctypes.c_void_p(ctypes.addressof(wsp)), 1, n, n, 0) == 0     # empty list: ok
     assert L.bfpq_is_fused(4, 64, 5, 64, 2, 4) == 0
     # packed-format entry points
     assert L.bfpq_compact24(one, one, one, 6, one, n) == -1                                     # code bytes not a multiple of 4
