@@ -279,11 +279,42 @@ def _prune_lists(tensors, a):
                                                          a['block_size'], a['mant_bits'], a['epsilon'])) for g in groups.values()]
 
 
+MANY_LANES = 3                       # streams a list of tensors without a list kernel is dealt to (the current one + side streams)
+MANY_LANES_MIN_BYTES = 24 << 20      # ... when at least two of its tensors are this large (smaller ones: the host call costs more than it hides)
+
+
+def _many_over_streams(tensors, fn):
+    """[fn(t) for t in tensors] for configurations that have no list form in the library (several launches per tensor: quantize-first
+    unstructured pruning, stochastic rounding, the 'int' format, N:8 on ragged rows ...).  The calls are independent, so large device
+    tensors are dealt round-robin to MANY_LANES streams -- one tensor's launch boundaries, ramps and tails beside the other tensors'
+    streaming, as the library's own list calls do it (native.PruneQuantizeList) -- with one fork and one join around the list."""
+    big = [t for t in tensors if t.device.type == "cuda" and t.numel() * t.element_size() >= MANY_LANES_MIN_BYTES]
+    if MANY_LANES < 2 or len(big) < 2 or len({t.device for t in big}) != 1 or any(t.device != big[0].device for t in tensors):
+        return [fn(t) for t in tensors]
+    dev = big[0].device
+    main = torch.cuda.current_stream(dev)
+    streams = [main] + native.aux_streams(dev, MANY_LANES - 1)
+    for s in streams[1:]:
+        s.wait_stream(main)
+    out = []
+    for i, t in enumerate(tensors):
+        s = streams[i % len(streams)]
+        with torch.cuda.stream(s):
+            y = fn(t)
+            if s is not main and y is not t:
+                y.record_stream(main)                       # (allocated on a side stream, consumed on the caller's)
+        out.append(y)
+    for s in streams[1:]:
+        main.wait_stream(s)
+    return out
+
+
 def float_to_bfp_blocked_many(tensors, identifier='', **bfp_args):
     """float_to_bfp_blocked (bfp_ops.py:124-149) for a LIST of tensors with one configuration -- e.g. every Linear weight of
     a model -- in as few launches as possible: one per 64 tensors per dtype/device for the 'bfp' format with structured or no
-    pruning and round-half-even; for unstructured pruning before quantization, two launches per tensor pipelined over two
-    streams (native.PruneQuantizeList); anything else is done tensor by tensor.  Returns the list of results in order."""
+    pruning and round-half-even (large tensors: a launch each, spread over two streams); for unstructured pruning before
+    quantization, two launches per tensor over four independent lanes (native.PruneQuantizeList); anything else is the
+    per-tensor call, large tensors dealt to a few streams (_many_over_streams).  Returns the list of results in order."""
     a = unpack_bfp_args(dict(bfp_args))
     tensors = list(tensors)
     sparsity = _select_sparsity(a['in_sparsity'], a['w_sparsity'], a['grad_sparsity'], identifier)
@@ -297,7 +328,7 @@ def float_to_bfp_blocked_many(tensors, identifier='', **bfp_args):
             and a['block_size'] > 0 and not bfp_args.get('sgd_update')
             and (not sparsity or (a['sparsity_mode'] == 'structured' and 0 < a['N'] <= a['M'])))
     if not lean:
-        return [float_to_bfp_blocked(t, **a, identifier=identifier, sgd_update=bool(bfp_args.get('sgd_update'))) for t in tensors]
+        return _many_over_streams(tensors, lambda t: float_to_bfp_blocked(t, **a, identifier=identifier, sgd_update=bool(bfp_args.get('sgd_update'))))
     nm = sparsity and a['N'] < a['M']
     f = _fast_quant(a['block_size'], a['mant_bits'], a['epsilon'], a['N'] if nm else 0, a['M'] if nm else 0, a['first'] == 's')
     out = [None] * len(tensors)

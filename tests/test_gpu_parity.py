@@ -1248,6 +1248,29 @@ def test_list_with_large_tensors_over_two_streams():
         assert torch.equal(a, b), f"one stream #{i}"
 
 
+def test_list_without_a_list_kernel_goes_over_streams():
+    """float_to_bfp_blocked_many for configurations the library has no list form for (quantize-first unstructured pruning, the 'int'
+    format, 4:8): large tensors are dealt to a few streams (bfp_ops._many_over_streams) -- same bytes as the per-tensor calls, also
+    from a non-default stream and with a small tensor in between."""
+    dt = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(9)
+    xs = [(torch.randn(r, k, generator=g, device=DEV) * 0.02).to(dt) for r, k in ((4096, 4096), (3072, 4096), (64, 256), (2048, 8192), (4096, 3072))]
+    for c in (cfg(w_sparsity=True, sparsity_mode='unstructured', sparsity_frac=0.4, first='q'),
+              cfg(sparsity_num_format='int', mant_bits=8),
+              cfg(w_sparsity=True, N=4, M=8)):
+        want = [bfp_ops.float_to_bfp_blocked(x, **c, identifier='w').clone() for x in xs]
+        got = bfp_ops.float_to_bfp_blocked_many(xs, identifier='w', **c)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert a.dtype == b.dtype and torch.equal(a, b), (c['sparsity_mode'], c['sparsity_num_format'], c['M'], i)
+        s1 = torch.cuda.Stream()
+        s1.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s1):
+            got = bfp_ops.float_to_bfp_blocked_many(xs, identifier='w', **c)
+        torch.cuda.current_stream().wait_stream(s1)
+        for i, (a, b) in enumerate(zip(got, want)):
+            assert torch.equal(a, b), ("side-stream caller", c['sparsity_mode'], c['sparsity_num_format'], c['M'], i)
+
+
 def test_prepared_list_reruns_in_place():
     """PreparedMany: descriptors and outputs bound once; run() after an in-place weight update gives the new results"""
     ws = [synth(64 + 8 * i, 256, torch.bfloat16, 0.5, seed=i).to(DEV) for i in range(5)]
