@@ -1,9 +1,10 @@
 """A/B harness: several builds of libbfpq.so in ONE process, interleaved rounds, hipGraph of L launches each.
-usage: python tools_dev/ab.py name=path.so ...   (headline workload)"""
-import ctypes, sys, statistics, torch
+usage: [NM=4:8] python tools_dev/ab.py name=path.so ...   (headline workload; NM: another N:M pattern)"""
+import ctypes, os, sys, statistics, torch
 sys.path.insert(0, '.')
 from quantization_sparsity_interplay_amd import native
 rows, cols, L, R, ROUNDS = 4096, 11008, 100, 8, 12
+NN, MM = (int(v) for v in os.environ.get("NM", "2:4").split(":"))
 dev = torch.device('cuda:0')
 libs = {}
 for a in sys.argv[1:]:
@@ -15,13 +16,13 @@ for a in sys.argv[1:]:
     libs[n] = lib
 ins = [(torch.randn(rows, cols, generator=torch.Generator().manual_seed(r)) * 0.02).to(torch.bfloat16).to(dev) for r in range(R)]
 outs = [torch.empty_like(x) for x in ins]
-win = native.exp_window_dev(torch.bfloat16, dev); lut = native.nm4_lut_dev(2, dev)
+win = native.exp_window_dev(torch.bfloat16, dev); lut = native.nm4_lut_dev(NN, dev) if MM == 4 else native.nm8_lut_dev(NN, dev)
 graphs = {}
 for n, lib in libs.items():
     def run():
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for i in range(L):
-            rc = lib.bfpq_quantize_nm(ins[i % R].data_ptr(), outs[i % R].data_ptr(), None, None, rows, cols, 2, 64, 3, 1e-8, 2, 4, 1, 0, 0,
+            rc = lib.bfpq_quantize_nm(ins[i % R].data_ptr(), outs[i % R].data_ptr(), None, None, rows, cols, 2, 64, 3, 1e-8, NN, MM, 1, 0, 0,
                                       win.data_ptr(), lut.data_ptr(), None, st)
             assert rc == 0, rc
     run(); torch.cuda.synchronize()
