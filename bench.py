@@ -433,8 +433,9 @@ def main():
                                                "(per-GPU work fixed: weak scaling of the path itself), eager"}
         del w_ins, w_outs
         # BASELINE config 4 as specified, at a reduced list: 16 LLaMA-13B q_proj weights [5120,5120], 50 % unstructured -> HBFP4, every rank
-        # its row slab of every weight; one histogram all-gather per tensor.  lanes = 1: tensor after tensor; lanes = 4: dealt to
-        # four streams, one tensor's exchange beside the others' kernels (dist.float_to_bfp_blocked_many_sharded)
+        # its row slab of every weight.  lanes = 1: tensor after tensor, one histogram all-gather each; lanes = 4: dealt to four streams,
+        # one tensor's exchange beside the others' kernels; one_exchange: all 16 histograms first, ONE all-gather of their folded copies
+        # (dist.float_to_bfp_blocked_many_sharded)
         if 5120 % world == 0 and esize == 2:
             gq = torch.Generator(device=dev).manual_seed(4321)
             q_slabs = [(torch.randn(5120 // world, 5120, generator=gq, device=dev) * 0.02).to(dtype) for _ in range(16)]
@@ -443,10 +444,15 @@ def main():
                                                                    "selection launch, histogram all-gather, resolve launch, prune + quantize launch per tensor"}
             for ln in (1, 4):
                 def list_step(i, ln=ln):
-                    qd.float_to_bfp_blocked_many_sharded(q_slabs, [5120] * 16, identifier='w', lanes=ln, **c4)
+                    qd.float_to_bfp_blocked_many_sharded(q_slabs, [5120] * 16, identifier='w', lanes=ln, exchange='tensor', **c4)
                 lwall, _ = timed_loop(list_step, 5, 2, False)
                 rec[f"ms_per_pass_lanes{ln}"] = max_over_ranks(lwall) * 1e3 / 5
-            rec["elems/s_lanes4"] = 16 * 5120 * 5120 / rec["ms_per_pass_lanes4"] * 1e3
+
+            def one_exchange_step(i):
+                qd.float_to_bfp_blocked_many_sharded(q_slabs, [5120] * 16, identifier='w', exchange='list', group_size=16, **c4)
+            lwall, _ = timed_loop(one_exchange_step, 5, 2, False)
+            rec["ms_per_pass_one_exchange"] = max_over_ranks(lwall) * 1e3 / 5            # ONE histogram all-gather for all 16 tensors
+            rec["elems/s_one_exchange"] = 16 * 5120 * 5120 / rec["ms_per_pass_one_exchange"] * 1e3
             extra["cfg4_sharded_list"] = rec
             del q_slabs
         _, k_ms = timed_loop(kernel_only, short, 5, False)

@@ -186,6 +186,15 @@ int bfpq_select_hist(const void* in_dev, int64_t numel, int dtype, int pass, int
 int bfpq_select_resolve(const void* in_dev, int64_t numel, int dtype, int pass, int64_t k,
                         const uint32_t* hist_all_dev /* [n_ranks][COPIES][ENTRIES] */, int n_ranks, int rank,
                         void* ws_dev, uint32_t* zero_hist_dev, void* stream);
+/* The same resolve launch over a gathered block of another shape (ABI 4): per rank `copies` histograms (1 ... BFPQ_SELECT_HIST_COPIES) of
+ * BFPQ_SELECT_HIST_ENTRIES words, rank r's set at hist_all_dev + r * rank_stride_words.  What a LIST of row-sharded tensors uses to get by with ONE
+ * exchange per radix pass for the whole list instead of one per tensor: every tensor's local histogram is launched first, the copies of each are
+ * summed (a tensor then sends 132 KB instead of 1 MB), the [tensors, ENTRIES] block is all-gathered in one collective, and tensor i resolves
+ * from hist_all_dev = gathered + i * ENTRIES with copies = 1, rank_stride_words = tensors * ENTRIES.  zero_hist_dev as above: the tensor's
+ * local 8-copy buffer, cleared for its next use.  bfpq_select_resolve(...) is the call with copies = 8, rank_stride_words = 8 * ENTRIES. */
+int bfpq_select_resolve_ex(const void* in_dev, int64_t numel, int dtype, int pass, int64_t k,
+                           const uint32_t* hist_all_dev, int n_ranks, int rank, int copies, int64_t rank_stride_words,
+                           void* ws_dev, uint32_t* zero_hist_dev, void* stream);
 int bfpq_select_reset(void* ws_dev, void* stream);
 int bfpq_threshold_apply(const void* in_dev, void* out_dev, int64_t numel, int dtype, void* ws_dev, void* stream);
 /* step 3 fused with the quantizer: out = Q(S_threshold(in)) in one pass over the tensor (first == 's',

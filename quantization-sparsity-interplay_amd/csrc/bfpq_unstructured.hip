@@ -297,9 +297,12 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist_lo16(const void* in
 constexpr int kResThreads = 256;
 template <int DT, bool FAST>
 __global__ void __launch_bounds__(kResThreads) k_select_resolve(const void* in, int64_t numel, int pass, int shift, int nbits, int first, int last,
-                                                                const uint32_t* hist_all, int n_ranks, int rank, int64_t k,
+                                                                const uint32_t* hist_all, int n_ranks, int rank, int nc, int64_t rstride, int64_t k,
                                                                 SelWs* ws, uint32_t* zero_buf, int own_hist)
 {
+    // hist_all: per rank `nc` histograms of BFPQ_SELECT_HIST_ENTRIES words, rank r's set at hist_all + r * rstride (the plain all-gather of the
+    // local buffers: nc = BFPQ_SELECT_HIST_COPIES, rstride = nc * ENTRIES; the list exchange folds the copies first: nc = 1, and a rank's
+    // row of the gathered [ranks, tensors, ENTRIES] block is `tensors * ENTRIES` words from the next rank's)
     constexpr int VEC = Traits<DT>::VEC;
     constexpr int NC = BFPQ_SELECT_HIST_COPIES;
     __shared__ uint32_t s_part[16];
@@ -307,8 +310,7 @@ __global__ void __launch_bounds__(kResThreads) k_select_resolve(const void* in, 
     const int t = threadIdx.x;
     bfpq_select_state* st = &ws->st;
     STAMP(1, 0);
-    if (own_hist) { hist_all = ws->hist[pass][0]; zero_buf = nullptr; n_ranks = 1; rank = 0; }
-    const int n_hists = n_ranks * NC;
+    if (own_hist) { hist_all = ws->hist[pass][0]; zero_buf = nullptr; n_ranks = 1; rank = 0; nc = NC; rstride = (int64_t)NC * BFPQ_SELECT_HIST_ENTRIES; }
     const int64_t n_items = (numel + VEC - 1) / VEC;
     const SegGeom g = seg_geom(n_items);
     // loads that depend on nothing go first: this segment-window word, the state of the previous pass
@@ -316,7 +318,12 @@ __global__ void __launch_bounds__(kResThreads) k_select_resolve(const void* in, 
     const uint32_t k_rem = first ? (uint32_t)k : (uint32_t)st->k_rem;
     const uint32_t prefix0 = first ? 0u : st->prefix, pmask0 = first ? 0u : st->prefix_mask;
     const int64_t k0 = first ? k : st->k;
-    auto sum_h = [&](int idx) { uint32_t s = 0; for (int r = 0; r < n_hists; r++) s += hist_all[(size_t)r * BFPQ_SELECT_HIST_ENTRIES + idx]; return s; };
+    auto sum_h = [&](int idx) {
+        uint32_t s = 0;
+        for (int r = 0; r < n_ranks; r++)
+            for (int c = 0; c < nc; c++) s += hist_all[(size_t)r * rstride + (size_t)c * BFPQ_SELECT_HIST_ENTRIES + idx];
+        return s;
+    };
     if (t < 12) s_res[t] = 0;                               // (k_rem == 0: digit 0, nothing in front of it)
     uint32_t total;
     if (nbits == 15) {
@@ -333,8 +340,8 @@ __global__ void __launch_bounds__(kResThreads) k_select_resolve(const void* in, 
         const int nbins = 1 << nbits;                       // 2048 or 512: eight or two contiguous bins per thread
         const int per = nbins / kResThreads;
         uint32_t v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mine = 0;
-        for (int r = 0; r < n_hists; r++) {                 // a thread's bins are contiguous: 16-byte / 8-byte loads per copy
-            const uint32_t* h = hist_all + (size_t)r * BFPQ_SELECT_HIST_ENTRIES + t * per;
+        for (int rc = 0; rc < n_ranks * nc; rc++) {         // a thread's bins are contiguous: 16-byte / 8-byte loads per copy
+            const uint32_t* h = hist_all + (size_t)(rc / nc) * rstride + (size_t)(rc % nc) * BFPQ_SELECT_HIST_ENTRIES + t * per;
             if (per == 8) {
                 const uint4 a4 = *reinterpret_cast<const uint4*>(h), b4 = *reinterpret_cast<const uint4*>(h + 4);
                 v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w; v[4] += b4.x; v[5] += b4.y; v[6] += b4.z; v[7] += b4.w;
@@ -369,7 +376,8 @@ __global__ void __launch_bounds__(kResThreads) k_select_resolve(const void* in, 
     }
     const uint32_t tau = prefix, need = k_rem - run;
     uint32_t tie_base = 0;
-    for (int r = 0; r < rank * NC; r++) tie_base += hist_all[(size_t)r * BFPQ_SELECT_HIST_ENTRIES + digit];
+    for (int r = 0; r < rank; r++)
+        for (int c = 0; c < nc; c++) tie_base += hist_all[(size_t)r * rstride + (size_t)c * BFPQ_SELECT_HIST_ENTRIES + digit];
     const int W = nbits == 15 ? kWinBins : (1 << nbits);
     // tie count of every segment from its window
     uint32_t tc = 0;
@@ -529,10 +537,12 @@ int bfpq_select_hist(const void* in, int64_t numel, int dtype, int pass, int64_t
     return launch_select_hist(in, numel, dtype, pass, k, numel_global, ws, hist, 0, stream);
 }
 
-int bfpq_select_resolve(const void* in, int64_t numel, int dtype, int pass, int64_t k,
-                        const uint32_t* hist_all, int n_ranks, int rank, void* ws, uint32_t* zero_hist, void* stream)
+int bfpq_select_resolve_ex(const void* in, int64_t numel, int dtype, int pass, int64_t k,
+                           const uint32_t* hist_all, int n_ranks, int rank, int copies, int64_t rank_stride_words,
+                           void* ws, uint32_t* zero_hist, void* stream)
 {
     if (!select_args_ok(in, numel, dtype, pass, k, ws) || (hist_all && (n_ranks < 1 || rank < 0 || rank >= n_ranks))) return BFPQ_E_ARG;
+    if (hist_all && (copies < 1 || copies > BFPQ_SELECT_HIST_COPIES || rank_stride_words < (int64_t)copies * BFPQ_SELECT_HIST_ENTRIES)) return BFPQ_E_ARG;
     if (k >= ((int64_t)1 << 32) || numel >= ((int64_t)1 << 32)) return BFPQ_E_UNSUPPORTED;
     if (numel == 0) return 0;                                 // an empty slab has nothing to prune (its histogram stayed zero)
     int shift, nbits;
@@ -544,12 +554,19 @@ int bfpq_select_resolve(const void* in, int64_t numel, int dtype, int pass, int6
     hipStream_t s = (hipStream_t)stream;
     SelWs* w = (SelWs*)ws;
 #define BFPQ_SR(DT, F) hipLaunchKernelGGL((k_select_resolve<DT, F>), dim3(g.G), dim3(kResThreads), 0, s, in, numel, pass, shift, nbits, first, last, \
-                                          hist_all, n_ranks, rank, k, w, zero_hist, hist_all ? 0 : 1)
+                                          hist_all, n_ranks, rank, copies, rank_stride_words, k, w, zero_hist, hist_all ? 0 : 1)
     if (dtype == BFPQ_F32) { if (fast) BFPQ_SR(BFPQ_F32, true); else BFPQ_SR(BFPQ_F32, false); }
     else if (dtype == BFPQ_F16) { if (fast) BFPQ_SR(BFPQ_F16, true); else BFPQ_SR(BFPQ_F16, false); }
     else { if (fast) BFPQ_SR(BFPQ_BF16, true); else BFPQ_SR(BFPQ_BF16, false); }
 #undef BFPQ_SR
     return (int)hipGetLastError();
+}
+
+int bfpq_select_resolve(const void* in, int64_t numel, int dtype, int pass, int64_t k,
+                        const uint32_t* hist_all, int n_ranks, int rank, void* ws, uint32_t* zero_hist, void* stream)
+{
+    return bfpq_select_resolve_ex(in, numel, dtype, pass, k, hist_all, n_ranks, rank, BFPQ_SELECT_HIST_COPIES,
+                                  (int64_t)BFPQ_SELECT_HIST_COPIES * BFPQ_SELECT_HIST_ENTRIES, ws, zero_hist, stream);
 }
 
 // single device: all launches of the selection.  16-bit dtypes: ONE (the histogram launch, whose last workgroup resolves);

@@ -145,17 +145,89 @@ def float_to_bfp_blocked_sharded(local, rows_total, group=None, gather=False, co
     return all_gather_rows(out, rows_total, group) if gather else out
 
 
+_list_ws = {}
+
+
+def _list_workspaces(device, n):
+    """n select workspaces of the device for the list exchange (one per tensor of a group: its windows live there from the
+    histogram launch to the apply launch); kept, they are 7.4 MB each"""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    pool = _list_ws.setdefault(idx, [])
+    while len(pool) < n:
+        pool.append(native.SelectWorkspace(torch.device("cuda", idx)))
+    return pool[:n]
+
+
+def _block_allgather(group):
+    """the ONE exchange per radix pass of a whole group of tensors: [n, ENTRIES] (copies folded) -> [world, n, ENTRIES]"""
+    def fn(block):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        allb = torch.empty((world,) + tuple(block.shape), dtype=block.dtype, device=block.device)
+        all_gather_into(allb, block.contiguous(), group)
+        return allb, world, rank
+    return fn
+
+
+def _many_sharded_one_exchange(locals_, rows_totals, group, gather, identifier, group_size, bfp_args):
+    """the fused unstructured path (prune, then quantize) of a list of row-sharded tensors with ONE histogram exchange per radix pass
+    and GROUP of tensors: all selection histograms of the group first, one all-gather of their folded copies (132 KB per tensor and
+    rank), all resolve launches, then the prune + quantize launches over two streams.  LLaMA-13B's 280 weights: 9 collectives of
+    ~4 MB per rank instead of 280 of 1 MB (each of which costs its full latency with nothing to run beside it)."""
+    n = len(locals_)
+    frac = bfp_args['sparsity_frac']
+    assert (frac > 0)
+    assert (bfp_args['block_size'] > 0)                                 # bfp_ops.py:130
+    mb = bfp_args['weight_mant_bits'] if bfp_args.get('sgd_update') else bfp_args['mant_bits']
+    dev = locals_[0].device
+    main = torch.cuda.current_stream(dev)
+    side = native.aux_streams(dev, 1)[0]
+    outs = [None] * n
+    for g0 in range(0, n, group_size):
+        idx = list(range(g0, min(n, g0 + group_size)))
+        ngs, ks = [], []
+        for i in idx:
+            cols = 1
+            for d in locals_[i].shape[1:]:
+                cols *= int(d)
+            ng = rows_totals[i] * cols
+            k = int(ng * frac)
+            if k > ng:
+                raise RuntimeError("selected index k out of range")     # what torch.topk raises in the reference
+            ngs.append(ng); ks.append(k)
+        wss = _list_workspaces(dev, len(idx))
+        native.select_threshold_list([locals_[i] for i in idx], ks, wss, ngs, _block_allgather(group))
+        side.wait_stream(main)
+        for j, i in enumerate(idx):
+            t = locals_[i]
+            if t.numel() == 0:
+                outs[i] = t.clone()
+                continue
+            s = side if (j & 1) else main
+            with torch.cuda.stream(s):
+                seed = bfp_ops._seed_for(bfp_args['rounding_mode'])
+                o = native.quantize_threshold(t, wss[j], bfp_args['block_size'], mb, bfp_args['epsilon'], stoch_seed=seed)[0]
+                outs[i] = bfp_ops._stoc_dtype(o.view(t.shape), bfp_args['rounding_mode'])
+                if s is side:
+                    outs[i].record_stream(main)
+        main.wait_stream(side)                                            # (also: the group's workspaces are free for the next group)
+    return [all_gather_rows(o, r, group) for o, r in zip(outs, rows_totals)] if gather else outs
+
+
 def float_to_bfp_blocked_many_sharded(locals_, rows_totals, group=None, gather=False, identifier='', lanes=4, compute=None, engine=None,
-                                      **bfp_args):
+                                      exchange='list', group_size=32, **bfp_args):
     """float_to_bfp_blocked_sharded for a LIST of row-sharded tensors -- every Linear weight of a model, each rank holding its
     row slab of every weight (BASELINE config 4 as specified: LLaMA-13B, 50 % unstructured, row-sharded).
     Structured / dense configurations have no exchange: the slabs go through one list call (bfp_ops.float_to_bfp_blocked_many:
     large slabs in launches of their own over two streams), then the optional all-gathers.
     Unstructured pruning has one histogram all-gather per tensor (three for fp32) between its launches; issued tensor after
-    tensor on one stream, every exchange would leave the device idle for its whole latency.  Here the tensors are dealt
-    round-robin to `lanes` streams (the current one and side streams, each with its own select workspace), so that the
-    exchange of one tensor runs beside the kernels of the others; the collectives are still ISSUED in list order on every
-    rank, which is all a communicator needs.  Results are byte-identical to the per-tensor call.
+    tensor on one stream, every exchange would leave the device idle for its whole latency.  Two remedies:
+      exchange='list' (default; prune-then-quantize configurations): ONE exchange per radix pass for a whole group of `group_size`
+        tensors -- all their selection histograms first, the copies of each folded, one all-gather, all resolve launches, then the
+        prune + quantize launches (_many_sharded_one_exchange; native.select_threshold_list);
+      exchange='tensor' (and every other configuration): the tensors are dealt round-robin to `lanes` streams (the current one and
+        side streams, each with its own select workspace), so that the exchange of one tensor runs beside the kernels of the
+        others; the collectives are still ISSUED in list order on every rank, which is all a communicator needs.
+    Results are byte-identical to the per-tensor call.
     compute / engine: as in float_to_bfp_blocked_sharded (CPU rehearsal of the protocol with stand-ins: tensor after tensor)."""
     locals_ = list(locals_)
     n = len(locals_)
@@ -167,6 +239,9 @@ def float_to_bfp_blocked_many_sharded(locals_, rows_totals, group=None, gather=F
     if not unstructured and on_gpu and compute is None:
         outs = bfp_ops.float_to_bfp_blocked_many(locals_, identifier=identifier, **bfp_args)
         return [all_gather_rows(o, r, group) for o, r in zip(outs, rows_totals)] if gather else outs
+    fused = (bfp_args.get('first') == 's' and bfp_args.get('sparsity_num_format') == 'bfp' and compute is None and engine is None)
+    if on_gpu and n >= 2 and exchange == 'list' and fused and len({(t.dtype, t.device) for t in locals_}) == 1:
+        return _many_sharded_one_exchange(locals_, rows_totals, group, gather, identifier, max(1, int(group_size)), bfp_args)
     if not on_gpu or lanes <= 1 or n < 2:
         return [float_to_bfp_blocked_sharded(t, r, group, gather, compute, engine, identifier=identifier, **bfp_args)
                 for t, r in zip(locals_, rows_totals)]

@@ -88,6 +88,7 @@ def load_library():
         L.bfpq_prune_quantize_list.argtypes = [vp, i32, i32, i32, i32, dbl, vp, vp, i32, vp, vp, i32]
         L.bfpq_select_hist.argtypes = [vp, i64, i32, i32, i64, i64, vp, vp, vp]
         L.bfpq_select_resolve.argtypes = [vp, i64, i32, i32, i64, vp, i32, i32, vp, vp, vp]
+        L.bfpq_select_resolve_ex.argtypes = [vp, i64, i32, i32, i64, vp, i32, i32, i32, i64, vp, vp, vp]
         L.bfpq_threshold_apply.argtypes = [vp, vp, i64, i32, vp, vp]
         L.bfpq_select_reset.argtypes = [vp, vp]
         L.bfpq_quantize_threshold.argtypes = [vp, vp, vp, vp, i64, i64, i32, i32, i32, dbl, i32, u64, vp, vp, vp, vp]
@@ -106,7 +107,7 @@ def load_library():
         L.bfpq_hbfp_linear_mx8_parts.argtypes = [i64, i64, i64]
         L.bfpq_hbfp_linear_mx8_splitk.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, i64, i32, vp]
         for name in ("bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_fake_quantize_list", "bfpq_is_fused", "bfpq_nm_sparsify",
-                     "bfpq_select_passes", "bfpq_select", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
+                     "bfpq_select_passes", "bfpq_select", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_resolve_ex", "bfpq_select_reset",
                      "bfpq_prune_quantize", "bfpq_prune_quantize_batched", "bfpq_prune_quantize_list",
                      "bfpq_threshold_apply", "bfpq_quantize_threshold", "bfpq_int_quantize", "bfpq_dequantize", "bfpq_hbfp_linear_slices",
                      "bfpq_hbfp_linear_decode", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled",
@@ -119,7 +120,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ("bfpq_hbfp_linear_mx8_parts", "bfpq_hbfp_linear_mx8_splitk", "bfpq_quantize_mx8", "bfpq_mx8_from_hbfp", "bfpq_hbfp_linear_mx8_ok", "bfpq_hbfp_linear_mx8", "bfpq_hbfp_linear_tiled_ok", "bfpq_hbfp_linear_decode_tiled", "bfpq_hbfp_linear_slices", "bfpq_hbfp_linear_decode", "bfpq_dequantize", "bfpq_tune", "bfpq_int_workspace_elems", "bfpq_int_quantize", "bfpq_select_ws_bytes", "bfpq_version", "bfpq_error_string", "bfpq_exp_window_host", "bfpq_nm4_lut_host", "bfpq_nm8_lut_host", "bfpq_compact24", "bfpq_expand24",
                     "bfpq_nm_prune_mask_host", "bfpq_quantize_nm", "bfpq_fake_quantize", "bfpq_fake_quantize_batched", "bfpq_fake_quantize_list", "bfpq_is_fused", "bfpq_nm_sparsify",
-                    "bfpq_select_passes", "bfpq_select", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_reset",
+                    "bfpq_select_passes", "bfpq_select", "bfpq_select_hist", "bfpq_select_resolve", "bfpq_select_resolve_ex", "bfpq_select_reset",
                     "bfpq_prune_quantize", "bfpq_prune_quantize_batched", "bfpq_prune_quantize_list",
                     "bfpq_threshold_apply", "bfpq_quantize_threshold")
 
@@ -492,6 +493,46 @@ def select_threshold(t, k, ws, numel_global=None, allgather=None):
             hist_all, R, rank = allgather(hist)
             check(L.bfpq_select_resolve(_ptr(src) if n else null, n, code, p, int(k), _ptr(hist_all), int(R), int(rank), _ptr(ws.ws),
                                         _ptr(hist), st), "bfpq_select_resolve")
+
+
+def select_threshold_list(ts, ks, wss, numel_globals, allgather):
+    """select_threshold for a LIST of row-sharded tensors of one dtype on one device with ONE exchange per radix pass for the whole
+    list (instead of one per tensor): every tensor's local histogram is launched first (its own workspace wss[i]), the 8 copies of each
+    are summed, allgather(block [n, ENTRIES]) -> (gathered [R, n, ENTRIES], R, rank) moves them all in one collective, and tensor i
+    resolves from its column of the gathered block (bfpq_select_resolve_ex: copies = 1, rank stride = n * ENTRIES).  A tensor whose
+    slab is empty keeps a zero row.  Same thresholds, tie bases and cuts as the per-tensor exchange (the sums are the same integers)."""
+    n = len(ts)
+    if n == 0:
+        return
+    L = load_library()
+    srcs = [t.contiguous() for t in ts]
+    for t in srcs:
+        require_device_tensor(t)
+        if t.dtype != srcs[0].dtype or t.device != srcs[0].device:
+            raise ValueError("select_threshold_list: the tensors of one list share device and dtype")
+    dev, code = srcs[0].device, DTYPE_CODE[srcs[0].dtype]
+    null = ctypes.c_void_p(0)
+    E = SELECT_HIST_ENTRIES
+    with torch.cuda.device(dev):
+        st = _stream(srcs[0])
+        for ws in wss[:n]:
+            if ws.dirty:
+                check(L.bfpq_select_reset(_ptr(ws.ws), st), "bfpq_select_reset")
+                ws.dirty = False
+        for p in range(L.bfpq_select_passes(code)):
+            hists = [ws.ext_hist() for ws in wss[:n]]          # zero on entry: the resolve launch clears them again
+            for src, k, ng, ws, h in zip(srcs, ks, numel_globals, wss, hists):
+                m = src.numel()
+                check(L.bfpq_select_hist(_ptr(src) if m else null, m, code, p, int(k), int(ng), _ptr(ws.ws), _ptr(h), st), "bfpq_select_hist")
+            block = torch.stack(hists).view(n, SELECT_HIST_COPIES, E).sum(dim=1, dtype=torch.int32)       # [n, E]: the copies folded
+            gathered, R, rank = allgather(block)
+            gathered = gathered.contiguous()
+            base = gathered.data_ptr()
+            for i, (src, k, ws, h) in enumerate(zip(srcs, ks, wss, hists)):
+                m = src.numel()
+                check(L.bfpq_select_resolve_ex(_ptr(src) if m else null, m, code, p, int(k), ctypes.c_void_p(base + 4 * i * E), int(R), int(rank),
+                                               1, n * E, _ptr(ws.ws), _ptr(h), st), "bfpq_select_resolve_ex")
+            del gathered
 
 
 def quantize_threshold(t, ws, block_size, mant_bits, epsilon, want_deq=True, code_bits=0, want_exp=False,

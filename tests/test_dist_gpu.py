@@ -99,9 +99,13 @@ def _worker(rank, world, port, backend, one_device, tmpdir):
             rts = [f.shape[0] for f in fulls]
             for cl in (_cfg(sparsity_mode='unstructured', sparsity_frac=0.5, first='s'), _cfg(sparsity_mode='unstructured', sparsity_frac=0.3, first='q'), _cfg()):
                 want = [bfp_ops.float_to_bfp_blocked(f, **cl, identifier='w') for f in fulls]
-                got = qd.float_to_bfp_blocked_many_sharded(slabs, rts, gather=True, identifier='w', lanes=3, **cl)
+                got = qd.float_to_bfp_blocked_many_sharded(slabs, rts, gather=True, identifier='w', lanes=3, exchange='tensor', **cl)
                 for i, (a, b) in enumerate(zip(got, want)):
                     assert torch.equal(bits(a), bits(b)), ("list form", dt, cl['sparsity_mode'], cl['first'], i)
+                # ONE exchange per radix pass for a group of tensors (groups of 2: three groups, the last one short)
+                got = qd.float_to_bfp_blocked_many_sharded(slabs, rts, gather=True, identifier='w', exchange='list', group_size=2, **cl)
+                for i, (a, b) in enumerate(zip(got, want)):
+                    assert torch.equal(bits(a), bits(b)), ("list form, one exchange per group", dt, cl['sparsity_mode'], cl['first'], i)
                 parts = qd.float_to_bfp_blocked_many_sharded(slabs, rts, gather=False, identifier='w', lanes=2, **cl)
                 for i, (a, b) in enumerate(zip(parts, want)):
                     assert torch.equal(bits(a), bits(qd.shard_rows(b, world, rank))), ("list form, slabs", dt, cl['sparsity_mode'], i)
