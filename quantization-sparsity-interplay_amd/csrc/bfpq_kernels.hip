@@ -754,8 +754,8 @@ int bfpq_fake_quantize(const bfpq_plan* p, const void* in, void* out, int64_t ro
 
 // Lanes of a list call: the caller's stream (lane 0) and up to kMaxLanes - 1 aux streams.  Every tensor that gets launches of its
 // own goes, whole, to the lane that has been given the fewest bytes so far; the lanes run side by side without any event between
-// them -- one fork (the aux lanes wait for what the caller's stream held at the call), taken when the first tensor goes to an aux
-// lane, and one join (the caller's stream waits for every aux lane that was used).  hipGraph-capturable from the caller's stream.
+// them -- one fork (the aux lanes wait for what the caller's stream held at the call; the event is recorded in front of the call's first
+// launch of this kind) and one join (the caller's stream waits for every aux lane that was used).  hipGraph-capturable from the caller's stream.
 constexpr int kMaxLanes = 8;
 struct Lanes {
     hipStream_t s[kMaxLanes];
@@ -763,8 +763,7 @@ struct Lanes {
     bool used[kMaxLanes];
     int n;
     hipEvent_t fork;
-    int err;
-    Lanes(void* stream, void* const* aux, int n_aux) : n(1), fork(nullptr), err(0)
+    Lanes(void* stream, void* const* aux, int n_aux) : n(1), fork(nullptr)
     {
         s[0] = (hipStream_t)stream;
         for (int i = 0; aux && i < n_aux && n < kMaxLanes; i++) {
