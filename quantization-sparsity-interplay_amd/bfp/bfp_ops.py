@@ -776,6 +776,7 @@ class _BFPModule:
         >= 32 tokens): the same block products, summed exactly inside a block and in fp32 across blocks instead of by the bf16
         library GEMM -- results agree with F.linear on the fake-quantised operands up to that summation order."""
         cache = WeightCache(self, matrix_unit=matrix_unit) if enabled else None
+        self._weight_cache = cache                               # (patch.prime_weight_caches fills it for a whole model in one list call)
         op = _get_bfp_op(self._functional, self._op_name, self.bfp_args, cache=cache)
         if hasattr(self, 'linear_op'):
             self.linear_op = op

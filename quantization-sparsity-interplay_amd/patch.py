@@ -37,6 +37,31 @@ def patch_linear_layers(model, bfp_args, skip=("lm_head", "classifier", "score")
     return patched
 
 
+def prime_weight_caches(model):
+    """Fill the (opt-in, inference-only) weight caches of every BFPLinear / BFPConv2d of `model` with ONE list call per configuration
+    (bfp_ops.float_to_bfp_blocked_many: large weights in launches of their own over several streams, small ones up to 64 per launch --
+    LLaMA-7B's 224 weights in 4.1 ms) instead of one call per module on its first forward.  Modules whose cache is off or not usable
+    right now (training mode, gradients being recorded, stochastic rounding) are left alone.  Returns the number of weights stored."""
+    groups = {}
+    for m in model.modules():
+        cache = getattr(m, '_weight_cache', None)
+        if cache is None or getattr(m, 'num_format', None) != 'bfp' or not isinstance(m, (bfp_ops.BFPLinear, bfp_ops.BFPConv2d)):
+            continue
+        with torch.no_grad():
+            if not cache.usable(m.weight, m.bfp_args) or m.weight.device.type != 'cuda':
+                continue
+        key = (m.weight.dtype, m.weight.device, tuple(sorted((k, repr(v)) for k, v in m.bfp_args.items())))
+        groups.setdefault(key, []).append(m)
+    n = 0
+    for mods in groups.values():
+        with torch.no_grad():
+            outs = bfp_ops.float_to_bfp_blocked_many([m.weight.detach() for m in mods], identifier='w', **dict(mods[0].bfp_args))
+            for m, o in zip(mods, outs):
+                m._weight_cache.store(m.weight, o, m.bfp_args)
+                n += 1
+    return n
+
+
 class PackedBFPLinear(torch.nn.Module):
     """Inference-only Linear whose weight lives in packed HBFP form (4-bit codes + one int8 exponent per block of 64:
     0.516 B per weight instead of 2) -- what a BFPLinear with w_sparsity / HBFP4 computes in its forward, with the weight

@@ -10,7 +10,7 @@ import torch
 
 import quantization_sparsity_interplay_amd as pkg
 from quantization_sparsity_interplay_amd.bfp import bfp_ops
-from quantization_sparsity_interplay_amd.patch import patch_linear_layers, pack_linear_layers, PackedBFPLinear
+from quantization_sparsity_interplay_amd.patch import patch_linear_layers, pack_linear_layers, prime_weight_caches, PackedBFPLinear
 from oracle import oracle as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -65,6 +65,30 @@ def test_patched_llama_layers_match_oracle(dtype):
                            wq.view(torch.int32 if dtype == torch.float32 else torch.int16)), n
     for h in hooks:
         h.remove()
+
+
+@pytest.mark.gpu
+def test_prime_weight_caches_in_one_list_call():
+    """patch.prime_weight_caches: every cached BFPLinear's weight through ONE list call; the first forward then hits every cache and gives
+    what the un-primed model gives; a model in training mode is left alone (the cache is inference-only)."""
+    args = pkg.BFPConfig.hbfp(4, 64, w_sparsity=True, N=2, M=4, sparsity_mode='structured').to_kwargs()
+    ids = torch.randint(0, 1000, (2, 16), device="cuda")
+    plain = _tiny_llama(torch.bfloat16).cuda()
+    patch_linear_layers(plain, args)
+    with torch.no_grad():
+        want = plain(ids).logits
+    model = _tiny_llama(torch.bfloat16).cuda()
+    patch_linear_layers(model, args, cache_weights=True)
+    mods = [m for m in model.modules() if isinstance(m, bfp_ops.BFPLinear)]
+    assert prime_weight_caches(model) == len(mods) == 14
+    with torch.no_grad():
+        got = model(ids).logits
+    assert all(m._weight_cache.hits == 1 and m._weight_cache.misses == 1 for m in mods)        # (the one miss is the priming store)
+    assert torch.equal(got, want)
+    model.train()
+    for m in mods:
+        m._weight_cache.invalidate()
+    assert prime_weight_caches(model) == 0
 
 
 @pytest.mark.gpu
