@@ -175,7 +175,7 @@ int bfpq_nm_sparsify(const void* in_dev, void* out_dev, int64_t rows, int64_t co
 #define BFPQ_SELECT_HIST_ENTRIES (32768 + 256)   /* fine bins, then (16-bit dtypes) 256 coarse bins of 128 */
 #define BFPQ_SELECT_HIST_COPIES 8                /* a device accumulates into 8 copies (cuts the contention of the flush) */
 #define BFPQ_SELECT_WS_BYTES (BFPQ_SELECT_STATE_BYTES + 4 * (12 + BFPQ_SELECT_HIST_COPIES * 512 + 3 * BFPQ_SELECT_HIST_COPIES * BFPQ_SELECT_HIST_ENTRIES + \
-                              2 * BFPQ_SELECT_MAX_SEGMENTS + 2 * BFPQ_SELECT_MAX_SEGMENTS * BFPQ_SELECT_WINDOW_BINS))
+                              3 * BFPQ_SELECT_MAX_SEGMENTS + 2 * BFPQ_SELECT_MAX_SEGMENTS * BFPQ_SELECT_WINDOW_BINS))
 
 int bfpq_select_passes(int dtype);
 int64_t bfpq_select_ws_bytes(void);

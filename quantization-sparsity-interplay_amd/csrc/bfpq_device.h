@@ -227,9 +227,11 @@ struct SelWs {
     uint32_t hist[3][BFPQ_SELECT_HIST_COPIES][BFPQ_SELECT_HIST_ENTRIES];
     uint32_t seg_ties[kMaxSeg];               // elements equal to tau per segment (resolve launch, window-miss path)
     uint32_t seg_win[kMaxSeg];                // first bin of the segment's window | bit 31: magnitudes outside the window exist | bit 30: 128-bin window
+    uint32_t seg_win2[kMaxSeg];               // the segment's SECOND window (fused launch): first bin | bit 30: there is one | bit 31: magnitudes outside both windows exist
     uint32_t windows[kMaxSeg][kWinBins];      // (the apply launch also dumps the ordinary workgroups' cut-segment tiles here)
-    uint32_t windows2[kMaxSeg][kWinBins];     // fp32's low-16 digit: a second window per segment at a position every workgroup derives from the
-                                              // state alone (where the threshold lies if the low bits are spread evenly); directly behind `windows`
+    uint32_t windows2[kMaxSeg][kWinBins];     // the second window per segment, directly behind `windows`: where the segment's quantile would lie if its rank were off
+                                              // by a segment's sampling error (atoms next to the threshold); fp32's low-16 digit: at a position every workgroup
+                                              // derives from the state alone (where the threshold lies if the low bits are spread evenly)
 };
 static_assert(sizeof(SelWs) == BFPQ_SELECT_WS_BYTES, "bfpq.h: BFPQ_SELECT_WS_BYTES");
 static_assert(offsetof(SelWs, hist) % 16 == 0 && offsetof(SelWs, windows) % 16 == 0 && offsetof(SelWs, coarse) % 16 == 0, "SelWs: 16-byte aligned arrays");

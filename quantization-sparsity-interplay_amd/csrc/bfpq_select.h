@@ -63,13 +63,20 @@ __device__ __forceinline__ void coarse_from_lds(const uint32_t* s_hist, uint32_t
 // coarse sums into one of the workspace's coarse-histogram copies, a 2048-bin window of the fine histogram around the segment's
 // own quantile (target_frac of its elements), and the window's position -- then draw the ticket.  True for the LAST workgroup
 // of the grid: everything every segment published is in memory when it returns.  fine(b): the segment's count of fine bin b.
-// clo2 >= 0: also a second window at coarse bin clo2 (a position all workgroups share).  s_res: 4 words.  1024 threads; nobody
-// waits for anybody here.
+// A SECOND window per segment (windows2 / seg_win2):
+//   clo2 >= 0: at coarse bin clo2, a position all workgroups share (fp32's low digit);
+//   clo2 <  0: where the segment's quantile would lie if its rank were off by what a segment of this size can be off by
+//     (+- 4 sqrt(elements)), when that is outside the first window.  A distribution with a heavy ATOM next to the threshold -- a
+//     tensor that is already half zeros pruned by half again -- has its quantile in the atom's bin in one segment and thousands
+//     of bins higher in the next; with one window per segment half of them could not answer for the global threshold's bin and
+//     were recounted by the last workgroup, one after the other (5.3 ms instead of 41 us on [5120,5120]).
+// s_res: 4 words.  1024 threads; nobody waits for anybody here.
 template <int NCB, class F>
 __device__ __forceinline__ bool seg_publish_and_ticket(const uint32_t* s_coarse, uint32_t* s_res, SelWs* ws, double target_frac, F&& fine, int clo2 = -1)
 {
     const int t = threadIdx.x;
     const int copy = blockIdx.x % BFPQ_SELECT_HIST_COPIES;
+    constexpr int WC = kWinBins / 128;                           // coarse bins per window
     if (t < NCB) { const uint32_t c = s_coarse[t]; if (c) atomicAdd(&ws->coarse[copy][t], c); }
     STAMP(0, 3);
     // window: the 16 coarse bins (2048 bins) around the one that holds the segment's own quantile (first wave: NCB / 64 coarse
@@ -81,32 +88,46 @@ __device__ __forceinline__ bool seg_publish_and_ticket(const uint32_t* s_coarse,
         for (int j = 0; j < PER; j++) { c[j] = s_coarse[t * PER + j]; mine += c[j]; }
         const uint32_t incl = wave_incl_scan(mine);
         const uint32_t seg_elems = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t excl = incl - mine;
+        auto coarse_of = [&](uint64_t rank) __attribute__((always_inline)) {   // the coarse bin that holds the element of this rank (wave-uniform result)
+            const bool hit = mine && excl <= rank && rank < (uint64_t)excl + mine;
+            uint32_t e = excl;
+            int A = t * PER;
+#pragma unroll
+            for (int j = 0; j < PER - 1; j++) { if (rank >= (uint64_t)e + c[j]) { e += c[j]; A = t * PER + j + 1; } else break; }
+            return (int)pick_lane(hit, (uint32_t)A);
+        };
+        auto place = [](int A) { int lo = A - WC / 2; return lo < 0 ? 0 : (lo > NCB - WC ? NCB - WC : lo); };
         uint64_t target = (uint64_t)((double)seg_elems * target_frac);                          // (an anchor, not a count)
         if (seg_elems && target >= seg_elems) target = seg_elems - 1;
-        const uint32_t excl = incl - mine;
-        const bool hit = mine && excl <= target && target < (uint64_t)excl + mine;
-        uint32_t e = excl;
-        int A = t * PER;
-#pragma unroll
-        for (int j = 0; j < PER - 1; j++) { if (target >= (uint64_t)e + c[j]) { e += c[j]; A = t * PER + j + 1; } else break; }
-        const int Aq = (int)pick_lane(hit, (uint32_t)A);
-        int clo = Aq - kWinBins / 256;
-        clo = clo < 0 ? 0 : (clo > NCB - kWinBins / 128 ? NCB - kWinBins / 128 : clo);
-        uint32_t inside = t < kWinBins / 128 ? s_coarse[clo + t] : 0u;
-        inside = wave_sum(inside);
+        const int clo = place(coarse_of(target));
+        int clob = clo2;                                                                        // second window: given, or from the rank band
+        if (clo2 < 0 && seg_elems) {
+            const uint64_t eps = 4ull * (uint64_t)__builtin_sqrtf((float)seg_elems) + 4ull;
+            const int A_lo = coarse_of(target > eps ? target - eps : 0ull), A_hi = coarse_of(target + eps < seg_elems ? target + eps : seg_elems - 1);
+            if (A_lo < clo) clob = place(A_lo);
+            else if (A_hi >= clo + WC) clob = place(A_hi);
+        }
+        // elements inside the first window, and inside the union of the two
+        const uint32_t in_a = wave_sum(t < WC ? s_coarse[clo + t] : 0u);
+        uint32_t in_b = 0;
+        if (clob >= 0) in_b = wave_sum((t < WC && (uint32_t)(clob + t - clo) >= (uint32_t)WC) ? s_coarse[clob + t] : 0u);   // (bins of the second window outside the first)
         if (t == 0) {
             s_res[0] = seg_elems ? (uint32_t)clo * 128u : 0u;
-            pub_store(&ws->seg_win[blockIdx.x], seg_elems ? (((uint32_t)clo * 128u) | (inside != seg_elems ? 0x80000000u : 0u)) : 0u);   // (empty segment: no window, nothing outside it)
+            s_res[2] = (seg_elems && clob >= 0) ? (uint32_t)clob * 128u + 1u : 0u;                                         // (+ 1: "there is one")
+            pub_store(&ws->seg_win[blockIdx.x], seg_elems ? (((uint32_t)clo * 128u) | (in_a != seg_elems ? 0x80000000u : 0u)) : 0u);   // (empty segment: no window, nothing outside it)
+            pub_store(&ws->seg_win2[blockIdx.x], (seg_elems && clob >= 0) ? (((uint32_t)clob * 128u) | 0x40000000u | (in_a + in_b != seg_elems ? 0x80000000u : 0u)) : 0u);
         }
     }
     __syncthreads();
     STAMP(0, 4);
-    const uint32_t lo = s_res[0];
+    const uint32_t lo = s_res[0], lo2p = s_res[2];
     pub_store(&ws->windows[blockIdx.x][t], fine(lo + (uint32_t)t));
     pub_store(&ws->windows[blockIdx.x][kSelThreads + t], fine(lo + (uint32_t)(kSelThreads + t)));
-    if (clo2 >= 0) {                                         // the second window (same for every segment: coarse bins clo2 .. clo2 + 15)
-        pub_store(&ws->windows2[blockIdx.x][t], fine((uint32_t)clo2 * 128u + (uint32_t)t));
-        pub_store(&ws->windows2[blockIdx.x][kSelThreads + t], fine((uint32_t)clo2 * 128u + (uint32_t)(kSelThreads + t)));
+    if (lo2p) {                                              // (block-uniform) the second window
+        const uint32_t lo2 = lo2p - 1u;
+        pub_store(&ws->windows2[blockIdx.x][t], fine(lo2 + (uint32_t)t));
+        pub_store(&ws->windows2[blockIdx.x][kSelThreads + t], fine(lo2 + (uint32_t)(kSelThreads + t)));
     }
     STAMP(0, 5);
     // publish: every storing wave drains, the workgroup meets, one lane draws the ticket
@@ -147,7 +168,8 @@ __device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int
     uint32_t* s_r = lds + 4624;          // [16]
     uint32_t* s_h = lds + 4640;          // [128]
     uint32_t* s_segwin = lds + 4768;     // [256]
-    uint32_t* s_cv = lds + 5024;         // [NCB]
+    uint32_t* s_cv = lds + 5024;         // [NCB <= 512]
+    uint32_t* s_segwin2 = lds + 5536;    // [256]
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     STAMP(2, 0);
     uint32_t cv = 0;
@@ -156,8 +178,9 @@ __device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int
         for (int c = 0; c < NC; c++) cv += pub_load(&ws->coarse[c][t]);
     }
     const uint32_t sw = t < g.G ? pub_load(&ws->seg_win[t]) : 0u;
+    const uint32_t sw2 = t < g.G ? pub_load(&ws->seg_win2[t]) : 0u;      // second window: first bin | bit 30: there is one | bit 31: elements outside BOTH windows exist
     __syncthreads();                                         // (the histogram's LDS is dead from here on)
-    if (t < kMaxSeg) s_segwin[t] = sw;
+    if (t < kMaxSeg) { s_segwin[t] = sw; s_segwin2[t] = sw2; }
     if (t < NCB) s_cv[t] = cv;
     __syncthreads();
     if (wv == 0) {                                           // coarse bins: NCB / 64 per lane
@@ -176,13 +199,13 @@ __device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int
     const uint32_t C = s_r[0], before = s_r[1];
     STAMP(2, 1);
     for (int i = t; i < NC * NCB; i += kSelThreads) ws->coarse[i / NCB][i % NCB] = 0u;        // zero for the next call
-    // (the second window, where there is one, sits at the same place in every segment: if it covers C, it answers for all of them)
-    const bool use2 = clo2 >= 0 && C - (uint32_t)clo2 < (uint32_t)(kWinBins / 128);
-    // segments whose window cannot answer for C
+    // segments of which neither window can answer for C (although they have elements outside them)
     int miss = 0;
-    if (!use2 && t < g.G) {
-        const uint32_t clo = (sw & 0x3fffffffu) >> 7;
-        if (!(C - clo < (uint32_t)(kWinBins / 128)) && (sw >> 31)) miss = 1;
+    if (t < g.G) {
+        const uint32_t clo = (sw & 0x3fffffffu) >> 7, clob = (sw2 & 0x3fffffffu) >> 7;
+        const bool has2 = (sw2 >> 30) & 1u;
+        const bool in_a = C - clo < (uint32_t)(kWinBins / 128), in_b = has2 && C - clob < (uint32_t)(kWinBins / 128);
+        if (!in_a && !in_b && ((has2 ? sw2 : sw) >> 31)) miss = 1;
     }
     if (__syncthreads_or(miss)) {
         if (t < kMaxSeg) s_tc[t] = (uint32_t)miss;
@@ -214,8 +237,9 @@ __device__ __forceinline__ void fused_resolve(const void* in, int64_t numel, int
         if (t < g.G) {
             const uint32_t w = s_segwin[t], clo = (w & 0x3fffffffu) >> 7;
             const bool narrow = (w >> 30) & 1u;
-            if (use2) off = (uint32_t)(kMaxSeg + t) * kWinBins + (C - (uint32_t)clo2) * 128u;             // (windows2 lies directly behind windows)
-            else if (narrow ? clo == C : C - clo < (uint32_t)(kWinBins / 128)) off = (uint32_t)t * kWinBins + (narrow ? 0u : (C - clo) * 128u);
+            const uint32_t w2 = s_segwin2[t], clob = (w2 & 0x3fffffffu) >> 7;
+            if (narrow ? clo == C : C - clo < (uint32_t)(kWinBins / 128)) off = (uint32_t)t * kWinBins + (narrow ? 0u : (C - clo) * 128u);
+            else if (((w2 >> 30) & 1u) && C - clob < (uint32_t)(kWinBins / 128)) off = (uint32_t)(kMaxSeg + t) * kWinBins + (C - clob) * 128u;   // (windows2 lies directly behind windows)
         }
         s_off[t] = off;
     }

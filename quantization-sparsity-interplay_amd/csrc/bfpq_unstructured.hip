@@ -44,8 +44,11 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
         // 16-bit dtypes: one pass over the whole 15-bit key (shift 0, no prefix to match): two keys per packed and/min,
         // unconditional LDS atomics; one-ahead prefetch with a clamped, unconditional load
         const uint32_t absm = T::ABS | (T::ABS << 16), nanc = (T::INF + 1u) | ((T::INF + 1u) << 16);
+        // Zeros are counted in a register and added once: a tensor that is already sparse sends half of a wave's atomics to ONE
+        // LDS word otherwise (52 % zeros: the launch took twice as long).
         const int64_t lastv = n_items - 1;
         int64_t item = i0 + t;
+        uint32_t zeros = 0;
         uint4 v = reinterpret_cast<const uint4*>(in)[item < lastv ? item : lastv];
         for (; item < i1; item += kSelThreads) {
             const int64_t pf = item + kSelThreads;
@@ -54,11 +57,13 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t k2 = pk_min_i16_s(d[j] & absm, nanc);
-                atomicAdd(&s_hist[k2 & 0xffffu], 1u);
-                atomicAdd(&s_hist[k2 >> 16], 1u);
+                const uint32_t ka = k2 & 0xffffu, kb = k2 >> 16;
+                if (ka) atomicAdd(&s_hist[ka], 1u); else zeros++;
+                if (kb) atomicAdd(&s_hist[kb], 1u); else zeros++;
             }
             v = nv;
         }
+        if (zeros) atomicAdd(&s_hist[0], zeros);
     } else {
         int64_t item = i0 + t;
         uint32_t cur[VEC], nxt[VEC];

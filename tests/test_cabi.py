@@ -30,7 +30,7 @@ def test_argument_validation_without_gpu():
     assert L.bfpq_select_hist(one, 64, native.BF16, 0, 65, 64, one, n, n) == -1                                         # k > numel
     assert L.bfpq_select_hist(one, 64, native.BF16, 0, 5, 1 << 33, one, n, n) == -2                                     # 32-bit counters
     assert L.bfpq_select_resolve(one, 64, native.BF16, 0, 5, one, 2, 2, one, n, n) == -1                                # rank >= n_ranks
-    assert L.bfpq_select_ws_bytes() == 80 + 4 * (12 + 8 * 512 + 3 * 8 * 33024 + 2 * 256 + 2 * 256 * 2048)
+    assert L.bfpq_select_ws_bytes() == 80 + 4 * (12 + 8 * 512 + 3 * 8 * 33024 + 3 * 256 + 2 * 256 * 2048)
     assert L.bfpq_select(one, 64, native.BF16, 65, one, n) == -1 and L.bfpq_select(one, 0, native.BF16, 0, one, n) == 0            # k > numel; empty
     assert L.bfpq_threshold_apply(one, one, 64, native.BF16, one, n) == -1                                               # in place: refused
     assert L.bfpq_threshold_apply(one, one, 0, native.BF16, one, n) == 0                                                # empty: no launch

@@ -1060,6 +1060,38 @@ def test_unstructured_window_miss_falls_back_to_recount():
         assert_bits_equal(bits(got), bits(_flat_order_prune(xc, 0.5)), torch.bfloat16, f"constant {val}")
 
 
+@pytest.mark.parametrize("dname", ["bf16", "f32"])
+def test_unstructured_on_already_sparse_tensors(dname):
+    """A heavy atom next to the threshold: a tensor that is already (about) half zeros, pruned by half again -- a pre-pruned checkpoint
+    going through the path on every forward.  The segment's own quantile then lies in the zero bin in one segment and thousands of
+    bins higher in the next; every segment publishes a SECOND window for that case (without it half the segments were recounted by the
+    last workgroup: 5.3 ms instead of 41 us on [5120,5120]).  Bit for bit against the engine's tie rule on the host, and the time of
+    one call is held to a generous bound so that the recount path cannot come back unnoticed."""
+    dt = DT[dname]
+    g = torch.Generator().manual_seed(11)
+    rows, cols = 2048, 4096
+    base = torch.randn(rows, cols, generator=g) * 0.02
+    for tag, keep in (("49.9 % zeros", 0.501), ("50.1 % zeros", 0.499), ("30 % zeros", 0.7), ("70 % zeros", 0.3)):
+        xc = (base * (torch.rand(rows, cols, generator=g) < keep)).to(dt)
+        x = xc.to(DEV)
+        for frac in (0.5, 0.3):
+            got = bfp_ops._unstructured_sparsity(x, 'cuda', frac)
+            assert_bits_equal(bits(got), bits(_flat_order_prune(xc, frac)), dt, f"{tag} frac={frac}")
+    # pruned by this engine, then pruned again at the same fraction (the threshold sits exactly at the zero / non-zero boundary)
+    x = (torch.randn(5120, 5120, generator=torch.Generator(device=DEV).manual_seed(3), device=DEV) * 0.02).to(dt)
+    once = bfp_ops._unstructured_sparsity(x, 'cuda', 0.5)
+    twice = bfp_ops._unstructured_sparsity(once, 'cuda', 0.5)
+    assert np.array_equal(bits(twice), bits(once)) and int((once == 0).sum()) >= x.numel() // 2
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        bfp_ops._unstructured_sparsity(once, 'cuda', 0.5)
+    e1.record()
+    torch.cuda.synchronize()
+    assert e0.elapsed_time(e1) / 10 < 1.0, f"{e0.elapsed_time(e1) / 10:.3f} ms per call: the serial recount path is back"
+
+
 @pytest.mark.parametrize("shape", [(13824, 5120), (5120, 13824)])
 def test_oracle_parity_cfg4_13b_mlp_shapes(shape):
     """cfg 4 at the LLaMA-13B MLP shapes (gate/up [13824,5120], down [5120,13824]) bf16, HBFP4 + 50 % unstructured,
