@@ -28,6 +28,7 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
     __shared__ uint2 s_mask[NM == 4 && VEC == 8 ? 736 : 1];      // 16-bit dtypes: AND masks for the two dwords of a group
     __shared__ uint8_t s_keep[NM == 4 && VEC == 4 ? 736 : 1];    // fp32: 4-bit keep mask
     __shared__ uint64_t s_kv[NM == 8 ? 8 * kThreads : 1];        // N:8: column per thread for the nth_element replay (rare)
+    __shared__ uint4 s_f32t[F32IMG ? kThreads / 64 : 1][F32IMG ? 128 : 1];   // fp32 image: a wave's 2 KB on their way to hole-free stores
     // (the tables are filled further down, behind the first tile's load: one memory round trip for everything)
 
     const bool do_quant = a.lpb > 0;
@@ -518,11 +519,21 @@ __device__ __forceinline__ void fused_flat_body(const FusedArgs& a, [[maybe_unus
             uint32_t f[VEC];
 #pragma unroll
             for (int j = 0; j < VEC; j++) f[j] = f2u(raw_to_f32<DT>((od[j >> 1] >> (16 * (j & 1))) & 0xffffu));
-            if (valid) {
-                uint4* dst = reinterpret_cast<uint4*>(a.out_codes) + item * 2;
-                dst[0] = make_uint4(f[0], f[1], f[2], f[3]);          // (plain stores: the two halves of a 32-byte piece meet in L2;
-                dst[1] = make_uint4(f[4], f[5], f[6], f[7]);          //  non-temporal ones measured 66.5 vs 58 us)
-            }
+            // A lane's eight results are 32 bytes; stored as they lie, each of the two store instructions of a wave writes 16 bytes of
+            // every 32 (measured on the 'int' format's kernels: launches up to 1.7 x slower, at random).  The wave's 2 KB go through a
+            // wave-private LDS tile instead and leave as two instructions of 1 KB without holes (a wave's items are consecutive:
+            // its tile starts at item - lane; LDS operations of one wave execute in order).
+            uint4* tile = &s_f32t[threadIdx.x >> 6][0];
+            const int lane = threadIdx.x & 63;
+            tile[2 * lane] = make_uint4(f[0], f[1], f[2], f[3]);
+            tile[2 * lane + 1] = make_uint4(f[4], f[5], f[6], f[7]);
+            const uint4 lo = tile[lane], hi = tile[64 + lane];        // lane l: bytes [16 l, 16 l + 16) of the first and of the second KB
+            uint4* dst = reinterpret_cast<uint4*>(a.out_codes) + (item - lane) * 2;
+            // the lane that holds item j's halves: lanes 2 (j - first) and 2 (j - first) + 1 of the first KB for j - first < 32, ...
+            const int64_t n_it = a.n_items;
+            const int64_t it_lo = item - lane + (lane >> 1), it_hi = it_lo + 32;
+            if (it_lo < n_it) dst[lane] = lo;
+            if (it_hi < n_it) dst[64 + lane] = hi;
             return;
         }
         if constexpr (DEQ_ONLY) {                                           // hot mode: exactly one store per item

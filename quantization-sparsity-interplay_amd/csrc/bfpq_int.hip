@@ -16,6 +16,7 @@
 // compiled with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "bfpq.h"
 #include "bfpq_common.h"
 
@@ -231,6 +232,134 @@ __global__ void __launch_bounds__(kT) k_int_cols_quant_vec(const void* in, float
     }
 }
 
+// Activation path, r03 form ([4096,4096] bf16: 39.7 -> 29.4 us through the C ABI, [16384,4096]: 142 -> 89 us = 56 % of 8 TB/s on 6 B/elem;
+// tools_dev/ab_int.py).  What the pair above cost: the quantize launch was ONE generation of workgroups that all loaded, then all
+// computed (a true division per element), then all stored -- three phases in a row -- and, the larger part, every store instruction
+// of a wave wrote 16 bytes of every 32 (a lane's eight fp32 results leave in two instructions): launches of 70-120 us at random on
+// [16384,4096] where the hole-free form below takes 60.
+//   k_int_cols_minmax_wide: 1024-thread workgroups, each 64 column groups wide, over row tiles of 16 R rows: wave w reads rows
+//     tile 16 R + k 16 + w, a workgroup walks tiles blockIdx.y, + gridDim.y, ... (about one workgroup per CU, the next tile's loads in
+//     flight while the current one is reduced), the 16 waves meet in LDS once at the end (row stride 72 words: lanes write
+//     consecutive words, the reducing threads read consecutive COLUMNS with a two-way conflict at most) and leave 2 x 64 VEC atomics
+//     per workgroup (one wave-instruction = 64 consecutive columns).
+//   k_int_cols_quant_flat: below.
+template <int DT, int R>
+__global__ void __launch_bounds__(1024) k_int_cols_minmax_wide(const void* in, int64_t outer, int64_t C, uint32_t* ws)
+{
+    constexpr int VEC = Traits<DT>::VEC;
+    constexpr int W = 16, LS = 72;                           // waves per workgroup; LDS row stride in words
+    const int64_t ipr = C / VEC;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t cg0 = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t cg = cg0 < ipr ? cg0 : ipr - 1;            // idle lanes repeat the last column group (their results are not used)
+    const uint4* src = reinterpret_cast<const uint4*>(in);
+    // row tiles of 16 R rows: this workgroup takes tiles blockIdx.y, blockIdx.y + gridDim.y, ...; the next tile's R loads are issued
+    // before the current tile is reduced.  Rows past the end repeat the last row: no extremum changes.
+    auto ld = [&](int64_t tile, int k) __attribute__((always_inline)) {
+        const int64_t r = tile * (W * R) + (int64_t)k * W + w;
+        return src[(r < outer ? r : outer - 1) * ipr + cg];
+    };
+    const int64_t n_tiles = (outer + W * R - 1) / (W * R);
+    uint4 q[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) q[k] = ld(blockIdx.y, k);
+    float mn[VEC], mx[VEC];
+    bool nan[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) { mn[j] = 0.0f; mx[j] = 0.0f; nan[j] = false; }
+    for (int64_t t = blockIdx.y; t < n_tiles; t += gridDim.y) {
+        uint4 nx[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) nx[k] = ld(t + gridDim.y, k);
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            float v[VEC];
+            if constexpr (VEC == 4) { v[0] = u2f(q[k].x); v[1] = u2f(q[k].y); v[2] = u2f(q[k].z); v[3] = u2f(q[k].w); }
+            else {
+                const uint32_t d[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+                for (int j = 0; j < 4; j++) { v[2 * j] = raw_to_f32<DT>(d[j] & 0xffffu); v[2 * j + 1] = raw_to_f32<DT>(d[j] >> 16); }
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; j++) { nan[j] |= v[j] != v[j]; mn[j] = fminf(mn[j], v[j]); mx[j] = fmaxf(mx[j], v[j]); }
+            q[k] = nx[k];
+        }
+    }
+    __shared__ uint32_t s_k[W][VEC * LS];                    // [wave][j * LS + lane]; minima first, then the (inverted) maxima: 36 KB
+    const int64_t col0 = (int64_t)blockIdx.x * 64 * VEC;
+#pragma unroll
+    for (int which = 0; which < 2; which++) {
+        if (which) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < VEC; j++) {
+            if (nan[j]) { mn[j] = u2f(0xffc00000u); mx[j] = u2f(0x7fc00000u); }
+            s_k[w][j * LS + lane] = which ? ~f_key(mx[j]) : f_key(mn[j]);
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < 64 * VEC; c += 1024) {
+            const int at = (c % VEC) * LS + c / VEC;
+            uint32_t k = s_k[0][at];
+#pragma unroll
+            for (int p = 1; p < W; p++) { const uint32_t o = s_k[p][at]; k = k < o ? k : o; }
+            if (col0 + c < C) atomicMin(&ws[(which ? C : 0) + col0 + c], k);
+        }
+    }
+}
+
+// The quantize launch as a FLAT stream: unit i = four adjacent elements, a workgroup's units are contiguous, the grid moves through
+// input and output as one compact front.  The host makes the grid stride a multiple of the units per row, so a thread meets ONE
+// column unit on every trip and keeps its four scales in registers; UNR units per trip, the next trip's loads issued before the current
+// units are quantized and stored.  Measured and dropped: q = rint(x * (1/scale)) with an exact fallback where the product lies
+// within 2^-21 |t| of a half-integer -- bit-identical and no faster (the launch is not bound by its divisions); write-through (sc1)
+// 16-byte stores, to spare the launch the write-back of the dirty L2 lines it leaves (~4 us at its end, seen as the duration of
+// the NEXT launch in a kernel trace) -- 47-55 us instead of 25: bulk write-through runs at the fabric's ~1.3 TB/s.
+// A thread's unit is FOUR elements -- one 16-byte fp32 store, so that every store instruction of a wave writes 1 KB without holes (with
+// eight elements per lane the two halves of every 32 bytes left in different instructions) -- read by one 8-byte (16-bit dtypes) or
+// 16-byte (fp32) load.
+template <int DT, int UNR>
+__global__ void __launch_bounds__(kT) k_int_cols_quant_flat(const void* in, float* out, int64_t n_units, int64_t upr, int64_t C,
+                                                            const uint32_t* ws, float maxq, float zero)
+{
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    using in_t = typename std::conditional<DT == BFPQ_F32, u4v, u2v>::type;
+    const int64_t stride = (int64_t)gridDim.x * kT;            // host: stride % upr == 0
+    const int64_t i0 = (int64_t)blockIdx.x * kT + threadIdx.x;
+    const int64_t cu = i0 % upr;                               // this thread's column unit on every trip
+    const in_t* src = reinterpret_cast<const in_t*>(in);
+    auto ld = [&](int64_t i) __attribute__((always_inline)) {  // unconditional, clamped: a load inside a branch makes hipcc wait for it at once
+        return __builtin_nontemporal_load(src + (i < n_units ? i : n_units - 1));
+    };
+    in_t a[UNR];
+#pragma unroll
+    for (int k = 0; k < UNR; k++) a[k] = ld(i0 + k * stride);
+    float scale[4];
+    {
+        const uint4 x = *reinterpret_cast<const uint4*>(ws + cu * 4), y = *reinterpret_cast<const uint4*>(ws + C + cu * 4);   // (C % 4 == 0, ws 16-byte aligned: host)
+        scale[0] = int_scale(key_f(x.x), key_f(~y.x), maxq); scale[1] = int_scale(key_f(x.y), key_f(~y.y), maxq);
+        scale[2] = int_scale(key_f(x.z), key_f(~y.z), maxq); scale[3] = int_scale(key_f(x.w), key_f(~y.w), maxq);
+    }
+    f4v* o = reinterpret_cast<f4v*>(out);
+    for (int64_t i = i0; i < n_units; i += UNR * stride) {
+        in_t n[UNR];
+#pragma unroll
+        for (int k = 0; k < UNR; k++) n[k] = ld(i + (UNR + k) * stride);
+#pragma unroll
+        for (int k = 0; k < UNR; k++) {
+            float v[4];
+            if constexpr (DT == BFPQ_F32) { v[0] = u2f(a[k].x); v[1] = u2f(a[k].y); v[2] = u2f(a[k].z); v[3] = u2f(a[k].w); }
+            else {
+                v[0] = raw_to_f32<DT>(a[k].x & 0xffffu); v[1] = raw_to_f32<DT>(a[k].x >> 16);
+                v[2] = raw_to_f32<DT>(a[k].y & 0xffffu); v[3] = raw_to_f32<DT>(a[k].y >> 16);
+            }
+            const f4v w = {int_q(v[0], scale[0], zero, maxq), int_q(v[1], scale[1], zero, maxq), int_q(v[2], scale[2], zero, maxq), int_q(v[3], scale[3], zero, maxq)};
+            if (i + k * stride < n_units) __builtin_nontemporal_store(w, o + i + k * stride);
+            a[k] = n[k];
+        }
+    }
+}
+
 // 4-D activation path: one wave per (outer, channel) segment of `inner` contiguous elements
 template <int DT>
 __global__ void __launch_bounds__(kT) k_int_seg_minmax(const void* in, int64_t outer, int64_t C, int64_t inner, uint32_t* ws)
@@ -326,34 +455,40 @@ __global__ void __launch_bounds__(kT) k_int_rows_vec(const void* in, float* out,
 template <int DT, int ITEMS>
 __global__ void __launch_bounds__(kT) k_int_rows_reg(const void* in, float* out, int64_t C, int64_t inner, float maxq, float zero)
 {
-    constexpr int VEC = Traits<DT>::VEC;
+    // r03: a thread's unit is FOUR elements (an 8-byte load for the 16-bit dtypes, one 16-byte fp32 store), ITEMS2 = 2 ITEMS of them per
+    // row: every store instruction of a wave writes 1 KB without holes (eight elements per lane left the two halves of every 32 bytes
+    // in different instructions: [4096,11008] bf16 54.3 us; this form: see profiles/r03d_suite.md)
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    using in_t = typename std::conditional<DT == BFPQ_F32, u4v, u2v>::type;
+    constexpr int N = DT == BFPQ_F32 ? ITEMS : 2 * ITEMS;          // units per thread
     __shared__ float s_mn[2][kT / 64], s_mx[2][kT / 64];
     __shared__ int s_nan[2][kT / 64];
-    const int64_t ipr = inner / VEC;                               // lane items per row, <= ITEMS * kT
+    const int64_t upr = inner / 4;                                 // units per row, <= N * kT
     const int w = threadIdx.x >> 6;
     int ph = 0;
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x, ph ^= 1) {
-        const uint4* row = reinterpret_cast<const uint4*>(in) + c * ipr;
-        uint4 q[ITEMS];
+        const in_t* row = reinterpret_cast<const in_t*>(in) + c * upr;
+        in_t q[N];
 #pragma unroll
-        for (int k = 0; k < ITEMS; k++) {                          // clamped, unconditional: all ITEMS loads in flight
+        for (int k = 0; k < N; k++) {                              // clamped, unconditional: all N loads in flight
             const int64_t i = (int64_t)k * kT + threadIdx.x;
-            q[k] = row[i < ipr ? i : ipr - 1];
+            q[k] = row[i < upr ? i : upr - 1];
         }
         float mn = 0.0f, mx = 0.0f;
         bool nan = false;
-        float v[ITEMS][VEC];
+        float v[N][4];
 #pragma unroll
-        for (int k = 0; k < ITEMS; k++) {
-            if constexpr (VEC == 4) { v[k][0] = u2f(q[k].x); v[k][1] = u2f(q[k].y); v[k][2] = u2f(q[k].z); v[k][3] = u2f(q[k].w); }
+        for (int k = 0; k < N; k++) {
+            if constexpr (DT == BFPQ_F32) { v[k][0] = u2f(q[k].x); v[k][1] = u2f(q[k].y); v[k][2] = u2f(q[k].z); v[k][3] = u2f(q[k].w); }
             else {
-                const uint32_t d[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
-#pragma unroll
-                for (int j = 0; j < 4; j++) { v[k][2 * j] = raw_to_f32<DT>(d[j] & 0xffffu); v[k][2 * j + 1] = raw_to_f32<DT>(d[j] >> 16); }
+                v[k][0] = raw_to_f32<DT>(q[k].x & 0xffffu); v[k][1] = raw_to_f32<DT>(q[k].x >> 16);
+                v[k][2] = raw_to_f32<DT>(q[k].y & 0xffffu); v[k][3] = raw_to_f32<DT>(q[k].y >> 16);
             }
 #pragma unroll
-            for (int j = 0; j < VEC; j++) { nan |= v[k][j] != v[k][j]; mn = fminf(mn, v[k][j]); mx = fmaxf(mx, v[k][j]); }
-        }                                                          // (clamped duplicates of the last item change no extremum)
+            for (int j = 0; j < 4; j++) { nan |= v[k][j] != v[k][j]; mn = fminf(mn, v[k][j]); mx = fmaxf(mx, v[k][j]); }
+        }                                                          // (clamped duplicates of the last unit change no extremum)
         wave_minmax(mn, mx, nan);
         if ((threadIdx.x & 63) == 0) { s_mn[ph][w] = mn; s_mx[ph][w] = mx; s_nan[ph][w] = nan; }
         __syncthreads();                                           // double-buffered by row parity: one barrier per row
@@ -361,16 +496,13 @@ __global__ void __launch_bounds__(kT) k_int_rows_reg(const void* in, float* out,
         for (int i = 0; i < kT / 64; i++) { mn = fminf(mn, s_mn[ph][i]); mx = fmaxf(mx, s_mx[ph][i]); nan |= s_nan[ph][i] != 0; }
         if (nan) { mn = u2f(0x7fc00000u); mx = mn; }
         const float scale = int_scale(mn, mx, maxq);
+        f4v* dst = reinterpret_cast<f4v*>(out) + c * upr;
 #pragma unroll
-        for (int k = 0; k < ITEMS; k++) {
+        for (int k = 0; k < N; k++) {
             const int64_t i = (int64_t)k * kT + threadIdx.x;
-            if (i < ipr) {
-                float o[VEC];
-#pragma unroll
-                for (int j = 0; j < VEC; j++) o[j] = int_q(v[k][j], scale, zero, maxq);
-                float4* dst = reinterpret_cast<float4*>(out) + (c * ipr + i) * (VEC / 4);
-                dst[0] = make_float4(o[0], o[1], o[2], o[3]);
-                if constexpr (VEC == 8) dst[1] = make_float4(o[4], o[5], o[6], o[7]);
+            if (i < upr) {
+                const f4v o = {int_q(v[k][0], scale, zero, maxq), int_q(v[k][1], scale, zero, maxq), int_q(v[k][2], scale, zero, maxq), int_q(v[k][3], scale, zero, maxq)};
+                dst[i] = o;
             }
         }
     }
@@ -459,29 +591,51 @@ int run_int(const void* in, float* out, int64_t outer, int64_t C, int64_t inner,
         return (int)hipGetLastError();
     }
     if (!ws) return BFPQ_E_ARG;
-    // min keys start at the top; the max keys are kept INVERTED (atomicMin on ~key) so that one fill serves both arrays
+    // min keys start at the top; the max keys are kept INVERTED (atomicMin on ~key) so that one fill serves both arrays.
+    // (A workspace the caller keeps all ones, refilled by the quantize launch's last workgroup -- a ticket per workgroup -- instead of
+    // the fill launch was built and measured: no faster on large tensors, 14.6 against 10.8 us on [1576,1024] f32: a thousand
+    // tickets on one address serialise at ~9 ns each, and the fill launch hides behind its predecessor's write-back.)
     hipLaunchKernelGGL(k_int_fill, dim3((unsigned)((2 * C + 4 * kT - 1) / (4 * kT) > 64 ? 64 : (2 * C + 4 * kT - 1) / (4 * kT))), dim3(kT), 0, s, ws, 2 * C);   // (hipMemsetAsync: a 4.9 us node)
     if (inner == 1 && C % Traits<DT>::VEC == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0) {
         const int64_t ipr = C / Traits<DT>::VEC;
-        const int64_t gx = (ipr + kT - 1) / kT;
-        int64_t rpc_mm, rpc_q;
-        rpc_mm = 0;
-        rpc_q = 16;                                                    // the quantize launch: one batch of 16 rows per thread
+        const int64_t gxw = (ipr + 63) / 64;
         {
-            // 64 column groups per workgroup; every wave ~16 rows: half the atomics of the old layout at twice its workgroups
-            const int64_t gxm = (ipr + 63) / 64;
-            int64_t gym = (outer + 4 * 16 - 1) / (4 * 16);
-            if (gym * gxm > 2048) gym = (2048 + gxm - 1) / gxm;
-            if (gym < 1) gym = 1;
-            if (gym > 65535) gym = 65535;
-            hipLaunchKernelGGL((k_int_cols_minmax_vec<DT>), dim3((unsigned)gxm, (unsigned)gym), dim3(kT), 0, s, in, outer, C, rpc_mm, ws);
+            // row tiles of 16 R rows; ~TG workgroups (two of 1024 threads fit a CU), every workgroup the same number of tiles where that is possible
+            const int64_t tg = 256;
+            const bool big = gxw * ((outer + 63) / 64) >= 128;
+            const int64_t n_tiles = big ? (outer + 63) / 64 : (outer + 31) / 32;
+            int64_t gy = tg / gxw;
+            if (gy < 1) gy = 1;
+            if (gy > n_tiles) gy = n_tiles;
+            gy = (n_tiles + (n_tiles + gy - 1) / gy - 1) / ((n_tiles + gy - 1) / gy);       // the fewest workgroups with that many trips
+            if (gy > 65535) gy = 65535;
+            if (big) hipLaunchKernelGGL((k_int_cols_minmax_wide<DT, 4>), dim3((unsigned)gxw, (unsigned)gy), dim3(1024), 0, s, in, outer, C, ws);
+            else hipLaunchKernelGGL((k_int_cols_minmax_wide<DT, 2>), dim3((unsigned)gxw, (unsigned)gy), dim3(1024), 0, s, in, outer, C, ws);
         }
-        const int64_t rows_per_launch = rpc_q * 65535;                 // (grid.y limit: more than a million rows go in several launches)
-        for (int64_t row0 = 0; row0 < outer; row0 += rows_per_launch) {
-            const int64_t n = outer - row0 < rows_per_launch ? outer - row0 : rows_per_launch;
-            hipLaunchKernelGGL((k_int_cols_quant_vec<DT>), dim3((unsigned)gx, (unsigned)((n + rpc_q - 1) / rpc_q)), dim3(kT), 0, s,
-                               (const void*)(reinterpret_cast<const char*>(in) + row0 * C * (int64_t)sizeof(typename Traits<DT>::raw_t)), out + row0 * C,
-                               n, C, rpc_q, (const uint32_t*)ws, maxq, zero);
+        const int64_t upr = C / 4;                                     // the flat launch counts in units of four elements
+        int64_t a = upr, b = kT;
+        while (b) { const int64_t t = a % b; a = b; b = t; }
+        const int64_t m = upr / a;                                     // its grid: a multiple of upr / gcd(upr, 256)
+        if (m <= 2048 && (reinterpret_cast<uintptr_t>(ws) & 15u) == 0) {
+            const int64_t n_units = outer * upr;
+            // workgroups (tools_dev/ab_int.py): a column count that divides the grid stride as it stands ran fastest with two per CU ([4096,4096]
+            // bf16: 29.4 us at 512, 31-32 at 768 / 1024); the others with many ([2048,11008]: 42.8 at 516, 38.2 at 2021; [2048,13824]: 51.2 / 45.8)
+            const int64_t tgt = m <= 4 ? 512 : 2048;
+            constexpr int UNR = DT == BFPQ_F32 ? 2 : 4;
+            int64_t G = (tgt + m - 1) / m * m;
+            const int64_t need = ((n_units + kT - 1) / kT + m - 1) / m * m;
+            if (G > need) G = need;
+            hipLaunchKernelGGL((k_int_cols_quant_flat<DT, UNR>), dim3((unsigned)G), dim3(kT), 0, s, in, out, n_units, upr, C, (const uint32_t*)ws, maxq, zero);
+        } else {
+            const int64_t gx = (ipr + kT - 1) / kT;
+            const int64_t rpc_q = 16;                                  // one batch of 16 rows per thread
+            const int64_t rows_per_launch = rpc_q * 65535;             // (grid.y limit: more than a million rows go in several launches)
+            for (int64_t row0 = 0; row0 < outer; row0 += rows_per_launch) {
+                const int64_t n = outer - row0 < rows_per_launch ? outer - row0 : rows_per_launch;
+                hipLaunchKernelGGL((k_int_cols_quant_vec<DT>), dim3((unsigned)gx, (unsigned)((n + rpc_q - 1) / rpc_q)), dim3(kT), 0, s,
+                                   (const void*)(reinterpret_cast<const char*>(in) + row0 * C * (int64_t)sizeof(typename Traits<DT>::raw_t)), out + row0 * C,
+                                   n, C, rpc_q, (const uint32_t*)ws, maxq, zero);
+            }
         }
     } else if (inner == 1) {
         int64_t chunks = (outer + 63) / 64;

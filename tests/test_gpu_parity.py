@@ -560,6 +560,38 @@ def test_int_format_oracle_at_model_shapes():
         assert_bits_equal(bits(got), bits(want), torch.float32, f"int {rows}x{cols} {dname} {ident}")
 
 
+def test_int_format_activations_grid_rule_and_capture():
+    """the 'int' ACTIVATION path (per-column min/max over all rows, int_ops.py:44-50): the wide min/max launch over row tiles, the flat
+    quantize launch whose grid is a multiple of (C/4) / gcd(C/4, 256) (one column unit per thread on every trip), the row-batch launch
+    behind it for column counts without such a grid, a NaN column, an all-zero column, a one-signed column, repeated calls, and a
+    captured call -- all bit for bit against the oracle"""
+    c = cfg(sparsity_num_format='int', mant_bits=8, block_size=32)
+    cases = ((4096, 4096, "bf16"), (300, 11008, "bf16"), (1031, 768, "f16"), (8 * 197, 1024, "f32"), (5, 4096, "bf16"), (3, 64, "f32"), (129, 8 * 2053, "bf16"),
+             (2, 4 * 521, "f32"), (700, 1000, "f16"), (64, 6, "f32"), (2500, 512, "bf16"))   # (C/4) / gcd: 4, 43, 3, 1, 4, 1, 2053 (row-batch launch), 521, 125, scalar kernels, 1
+    for rows, cols, dname in cases:
+        dt = DT[dname]
+        xc = synth(rows, cols, dt, 1.0, seed=rows + cols)
+        if rows == 300:
+            xc[7, 40] = float('nan'); xc[:, 41] = 0; xc[:, 42] = xc[:, 42].abs()       # a NaN column, a zero column, a one-signed column
+        want = bits(O.float_to_bfp_blocked(xc, **c, identifier='in'))
+        x = xc.to(DEV)
+        for rep in range(2):
+            got = bfp_ops.float_to_bfp_blocked(x, **c, identifier='in')
+            assert got.dtype == torch.float32
+            assert_bits_equal(bits(got), want, torch.float32, f"int act [{rows},{cols}] {dname} call {rep}")
+    x = synth(512, 4096, torch.bfloat16, 1.0, seed=5).to(DEV)
+    want = bits(O.float_to_bfp_blocked(x.cpu(), **c, identifier='in'))
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        bfp_ops.float_to_bfp_blocked(x, **c, identifier='in')
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            y = bfp_ops.float_to_bfp_blocked(x, **c, identifier='in')
+        g.replay(); g.replay()
+    torch.cuda.synchronize()
+    assert_bits_equal(bits(y), want, torch.float32, "int act captured")
+
+
 def test_random_configs_vs_oracle():
     """120 seeded random (shape, dtype, block, mantissa, N:M / unstructured, order) cases: exercises the dispatch
     between the fused kernel, the threshold kernel and the ragged-row fallbacks against the oracle"""
