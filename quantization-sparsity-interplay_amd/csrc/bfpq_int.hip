@@ -8,9 +8,11 @@
 //                                                                             a wave or a workgroup owns a channel,
 //                                                                             reduces min/max, then quantizes it;
 //                                                                             the second read of the row is L2-served)
-//   2-D/3-D activation outer = rows, C = last dim,  inner = 1              -> k_int_cols_minmax (+ atomics on
+//   2-D/3-D activation outer = rows, C = last dim,  inner = 1              -> k_int_cols_minmax_wide (+ atomics on
 //                                                                             order-preserving integer keys:
-//                                                                             deterministic) / k_int_cols_quant
+//                                                                             deterministic) / k_int_cols_quant_flat
+//                                                                             (C % 4 != 0 or unaligned: k_int_cols_minmax /
+//                                                                             k_int_cols_quant; no flat grid: k_int_cols_quant_vec)
 //   4-D activation     outer = N,    C = shape[1],  inner = H*W            -> k_int_seg_minmax / k_int_seg_quant
 // All fp32 arithmetic is single IEEE operations in the reference's order (x / scale is a true division),
 // compiled with -ffp-contract=off.
@@ -147,50 +149,6 @@ __device__ __forceinline__ void load_vec_f(const void* in, int64_t item, float* 
         const uint32_t d[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int j = 0; j < 4; j++) { v[2 * j] = raw_to_f32<DT>(d[j] & 0xffffu); v[2 * j + 1] = raw_to_f32<DT>(d[j] >> 16); }
-    }
-}
-
-// A workgroup = 64 adjacent column groups (one wave's width: 1 KB of a row) x 4 row lanes (its 4 waves); wave w reads the rows
-// 4 blockIdx.y + w, + 4 gridDim.y, ... so that the grid moves through the tensor as a compact front.  The four waves meet in LDS and
-// leave 64 VEC x 2 atomics per workgroup (one wave-instruction = 64 consecutive columns; lane-strided atomics are an order of
-// magnitude slower, MI355X_MICROARCH.md): four times the workgroups of a 256-column-group layout for the same number of atomics.
-template <int DT>
-__global__ void __launch_bounds__(kT) k_int_cols_minmax_vec(const void* in, int64_t outer, int64_t C, int64_t rows_per_chunk, uint32_t* ws)
-{
-    constexpr int VEC = Traits<DT>::VEC;
-    constexpr int W = kT / 64;
-    const int64_t ipr = C / VEC;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t cg = (int64_t)blockIdx.x * 64 + lane;
-    const int64_t r0 = (int64_t)blockIdx.y * W + w, rstep = (int64_t)gridDim.y * W;
-    const int64_t r1 = cg < ipr ? outer : r0;              // idle lanes: empty range
-    float mn[VEC], mx[VEC];
-    bool nan[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; j++) { mn[j] = 0.0f; mx[j] = 0.0f; nan[j] = false; }
-#pragma unroll 8
-    for (int64_t r = r0; r < r1; r += rstep) {             // independent loads: unrolled so that several are in flight
-        float v[VEC];
-        load_vec_f<DT>(in, r * ipr + cg, v);
-#pragma unroll
-        for (int j = 0; j < VEC; j++) { nan[j] |= v[j] != v[j]; mn[j] = fminf(mn[j], v[j]); mx[j] = fmaxf(mx[j], v[j]); }
-    }
-    __shared__ uint32_t s_mn[W][64 * VEC], s_mx[W][64 * VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; j++) {
-        if (nan[j]) { mn[j] = u2f(0xffc00000u); mx[j] = u2f(0x7fc00000u); }
-        s_mn[w][lane * VEC + j] = f_key(mn[j]);
-        s_mx[w][lane * VEC + j] = ~f_key(mx[j]);            // (max keys inverted: one atomicMin serves both arrays)
-    }
-    __syncthreads();
-    const int64_t col0 = (int64_t)blockIdx.x * 64 * VEC;
-    for (int i = threadIdx.x; i < 2 * 64 * VEC; i += kT) {  // 64 VEC minima, then 64 VEC (inverted) maxima: consecutive columns per wave-instruction
-        const int which = i / (64 * VEC), c = i % (64 * VEC);
-        const uint32_t(*src)[64 * VEC] = which ? s_mx : s_mn;
-        uint32_t k = src[0][c];
-#pragma unroll
-        for (int q = 1; q < W; q++) k = k < src[q][c] ? k : src[q][c];
-        if (col0 + c < C) atomicMin(&ws[(which ? C : 0) + col0 + c], k);
     }
 }
 
