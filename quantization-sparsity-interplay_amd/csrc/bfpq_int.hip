@@ -50,6 +50,30 @@ __device__ __forceinline__ float int_q(float x, float scale, float zero, float m
     return scale * (q - zero);                             //                                      :8
 }
 
+// Four elements at once without the division where that is provably the same: t = x * (1 / scale) lies within 3 ulp-halves
+// (< 2^-22 |t|) of the correctly rounded quotient x / scale, so rint(t) == rint(x / scale) unless t is that close to a
+// half-integer; a lane whose element is (within 2^-21 |t|, or not finite: NaN / inf land there too) makes its WAVE redo the
+// unit with the true division.  The channel's extreme element sits exactly on +-(maxq / 2) and always does.  Everything behind
+// the rint is the reference's own sequence (clamp as one v_med3: the operands are finite here).  Used by the per-row kernel (75 % busy
+// issuing vector instructions with the division, profiles/r03d_pmc_int.md): [4096,11008] bf16 53.5 -> 52.4 us, [4096,4096] f32 26.8 -> 25.2 us
+// interleaved; the per-column quantize launch measured SLOWER with it and keeps the division.
+__device__ __forceinline__ void int_q4(const float* v, const float* scale, const float* rcp, float zero, float maxq, float* r)
+{
+    bool risky = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float t = v[j] * rcp[j];
+        const float n = rintf(t);
+        const float away = 0.5f - fabsf(t - n);                // distance to the nearest half-integer (t - n is exact)
+        risky |= !(away > fabsf(t) * 4.76837158e-7f);           // 2^-21 |t|
+        r[j] = scale[j] * (__builtin_amdgcn_fmed3f(n + zero, 0.0f, maxq) - zero);
+    }
+    if (__any(risky)) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[j] = int_q(v[j], scale[j], zero, maxq);
+    }
+}
+
 template <int DT> __device__ __forceinline__ float ldf(const void* in, int64_t i)
 {
     using raw_t = typename Traits<DT>::raw_t;
@@ -267,8 +291,9 @@ __global__ void __launch_bounds__(1024) k_int_cols_minmax_wide(const void* in, i
 // The quantize launch as a FLAT stream: unit i = four adjacent elements, a workgroup's units are contiguous, the grid moves through
 // input and output as one compact front.  The host makes the grid stride a multiple of the units per row, so a thread meets ONE
 // column unit on every trip and keeps its four scales in registers; UNR units per trip, the next trip's loads issued before the current
-// units are quantized and stored.  Measured and dropped: q = rint(x * (1/scale)) with an exact fallback where the product lies
-// within 2^-21 |t| of a half-integer -- bit-identical and no faster (the launch is not bound by its divisions); write-through (sc1)
+// units are quantized and stored.  Measured and dropped: q = rint(x * (1/scale)) with an exact fallback (int_q4, which the
+// per-row kernel uses) -- bit-identical and SLOWER here, before and after the stores lost their holes ([4096,4096] bf16 32.4 against 29.3 us,
+// [16384,4096] 96.2 against 88.8), although the counters show the launch 64 % busy issuing vector instructions; write-through (sc1)
 // 16-byte stores, to spare the launch the write-back of the dirty L2 lines it leaves (~4 us at its end, seen as the duration of
 // the NEXT launch in a kernel trace) -- 47-55 us instead of 25: bulk write-through runs at the fabric's ~1.3 TB/s.
 // A thread's unit is FOUR elements -- one 16-byte fp32 store, so that every store instruction of a wave writes 1 KB without holes (with
@@ -453,14 +478,16 @@ __global__ void __launch_bounds__(kT) k_int_rows_reg(const void* in, float* out,
 #pragma unroll
         for (int i = 0; i < kT / 64; i++) { mn = fminf(mn, s_mn[ph][i]); mx = fmaxf(mx, s_mx[ph][i]); nan |= s_nan[ph][i] != 0; }
         if (nan) { mn = u2f(0x7fc00000u); mx = mn; }
-        const float scale = int_scale(mn, mx, maxq);
+        const float scale = int_scale(mn, mx, maxq), rcp = 1.0f / scale;
+        const float sc4[4] = {scale, scale, scale, scale}, rc4[4] = {rcp, rcp, rcp, rcp};
         f4v* dst = reinterpret_cast<f4v*>(out) + c * upr;
 #pragma unroll
         for (int k = 0; k < N; k++) {
             const int64_t i = (int64_t)k * kT + threadIdx.x;
+            float r[4];
+            int_q4(v[k], sc4, rc4, zero, maxq, r);             // (outside the branch: the wave votes)
             if (i < upr) {
-                const f4v o = {int_q(v[k][0], scale, zero, maxq), int_q(v[k][1], scale, zero, maxq), int_q(v[k][2], scale, zero, maxq), int_q(v[k][3], scale, zero, maxq)};
-                dst[i] = o;
+                dst[i] = (f4v){r[0], r[1], r[2], r[3]};
             }
         }
     }

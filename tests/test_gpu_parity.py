@@ -592,6 +592,33 @@ def test_int_format_activations_grid_rule_and_capture():
     assert_bits_equal(bits(y), want, torch.float32, "int act captured")
 
 
+def test_int_format_weights_on_rounding_boundaries():
+    """the per-row 'int' kernel rounds with x * (1 / scale) where that provably equals x / scale and redoes a wave's unit with the true division
+    otherwise: rows built so that MANY elements sit exactly on half-integers of the grid (x = (n + 0.5) * scale with scale a power of two or
+    scale = 2 max / 255 from a row maximum chosen to make it so), one ulp beside them, on +-max, zeros, inf / NaN rows -- bit for bit against the oracle"""
+    c = cfg(sparsity_num_format='int', mant_bits=8, block_size=32)
+    g = torch.Generator().manual_seed(77)
+    for dname, dt in DT.items():
+        rows, cols = 64, 2048
+        x = torch.zeros(rows, cols, dtype=torch.float32)
+        for r in range(rows):
+            mx = float(2.0 ** (r % 7 - 3)) * (255.0 if r % 2 == 0 else 1.0 + (r % 5) / 8.0)       # even rows: scale = 2 mx / 255 is a power of two
+            n = torch.randint(-127, 127, (cols,), generator=g).float()
+            scale = 2.0 * mx / 255.0
+            x[r] = (n + 0.5) * scale                                                                # half-integers of the row's grid (before the dtype rounds them)
+            x[r, :8] = torch.tensor([mx, -mx, 0.0, -0.0, mx * 0.5, -mx * 0.5, scale * 0.5, -scale * 1.5])
+        xc = x.to(dt)
+        b = bits(xc).reshape(rows, cols)
+        absmask = 0x7FFFFFFF if dt == torch.float32 else 0x7FFF
+        b[:, 1024:1536] += 1                                       # one ulp above, and
+        b[:, 1536:] = np.where((b[:, 1536:] & absmask) > 0, b[:, 1536:] - 1, b[:, 1536:])   # one ulp below the pattern (magnitude-wise)
+        xc = from_bits(b, dt).view(rows, cols).clone()
+        xc[60, 100] = float('inf'); xc[61, 7] = float('nan'); xc[62] = 0; xc[63] = -xc[63].abs()
+        got = bfp_ops.float_to_bfp_blocked(xc.to(DEV), **c, identifier='w')
+        want = O.float_to_bfp_blocked(xc, **c, identifier='w')
+        assert_bits_equal(bits(got), bits(want), torch.float32, f"int weights on rounding boundaries {dname}")
+
+
 def test_random_configs_vs_oracle():
     """120 seeded random (shape, dtype, block, mantissa, N:M / unstructured, order) cases: exercises the dispatch
     between the fused kernel, the threshold kernel and the ragged-row fallbacks against the oracle"""

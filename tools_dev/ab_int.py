@@ -1,12 +1,15 @@
 """The 'int' per-column activation path through the C ABI (bfpq_int_quantize: fill + min/max + quantize launches), hipGraph of L calls over R rotating
 inputs.  Development builds read BFPQ_INT_QG / BFPQ_INT_MG (workgroup targets of the quantize / min-max launch).
-usage: python tools_dev/ab_int.py [rows cols dtype]"""
+usage: python tools_dev/ab_int.py [rows cols dtype] [weight] [name=path.so ...]   (weight: the per-row form, outer = 1; builds interleaved in one process)"""
 import ctypes, os, sys, statistics, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quantization_sparsity_interplay_amd import native
-rows = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-cols = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-dt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[sys.argv[3] if len(sys.argv) > 3 else 'bf16']
+pos = [a for a in sys.argv[1:] if '=' not in a and a != 'weight']
+weight = 'weight' in sys.argv
+rows = int(pos[0]) if len(pos) > 0 else 4096
+cols = int(pos[1]) if len(pos) > 1 else 4096
+dname = pos[2] if len(pos) > 2 else 'bf16'
+dt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[dname]
 L, R, ROUNDS = 40, 8, 9
 dev = torch.device('cuda:0')
 lib = native.load_library()
@@ -15,13 +18,22 @@ outs = [torch.empty(rows, cols, dtype=torch.float32, device=dev) for _ in range(
 n_ws = int(lib.bfpq_int_workspace_elems(cols))
 ws_any = torch.empty(n_ws, dtype=torch.int32, device=dev)
 ws_kept = torch.full((n_ws,), -1, dtype=torch.int32, device=dev)
-variants = {'int': (lib.bfpq_int_quantize, ws_any)}
+variants = {}
+for a in sys.argv[1:]:
+    if '=' in a:
+        n, p = a.split('=')
+        l2 = ctypes.CDLL(os.path.abspath(p))
+        l2.bfpq_int_quantize.argtypes = lib.bfpq_int_quantize.argtypes
+        l2.bfpq_int_quantize.restype = ctypes.c_int
+        variants[n] = (l2.bfpq_int_quantize, ws_any)
+if not variants: variants = {'int': (lib.bfpq_int_quantize, ws_any)}
+outer, C, inner = (1, rows, cols) if weight else (rows, cols, 1)
 graphs, ref = {}, None
 for n, (fn, ws) in variants.items():
     def run():
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for i in range(L):
-            rc = fn(ins[i % R].data_ptr(), outs[i % R].data_ptr(), rows, cols, 1, native.DTYPE_CODE[dt], 8, ws.data_ptr(), st)
+            rc = fn(ins[i % R].data_ptr(), outs[i % R].data_ptr(), outer, C, inner, native.DTYPE_CODE[dt], 8, ws.data_ptr(), st)
             assert rc == 0, rc
     for o in outs: o.zero_()
     run(); torch.cuda.synchronize()
@@ -42,4 +54,4 @@ for r in range(ROUNDS):
 bytes_ = rows * cols * (ins[0].element_size() + 4)
 for n, t in times.items():
     med = statistics.median(t)
-    print(f"[{rows},{cols}] {sys.argv[3] if len(sys.argv) > 3 else 'bf16'} {n:6s} median {med:6.2f} us  min {min(t):6.2f}  -> {bytes_/med/1e3:7.1f} GB/s ({bytes_/med/1e3/8000*100:4.1f}% of 8 TB/s)")
+    print(f"[{rows},{cols}] {dname}{' weight' if weight else ''} {n:6s} median {med:6.2f} us  min {min(t):6.2f}  -> {bytes_/med/1e3:7.1f} GB/s ({bytes_/med/1e3/8000*100:4.1f}% of 8 TB/s)")
