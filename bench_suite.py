@@ -35,6 +35,7 @@ CASES = [
     ("cfg4 13B q_proj [5120,5120] bf16 HBFP4 + 50% unstructured s", 5120, 5120, "bf16", 4, dict(w_sparsity=True, sparsity_mode='unstructured')),
     ("cfg4 13B gate [13824,5120] bf16 HBFP4 + 50% unstructured s", 13824, 5120, "bf16", 4, dict(w_sparsity=True, sparsity_mode='unstructured')),
     ("cfg4 13B q_proj f32 HBFP4 + 50% unstructured s", 5120, 5120, "f32", 8, dict(w_sparsity=True, sparsity_mode='unstructured')),
+    ("cfg4 13B q_proj [5120,5120] bf16 HBFP4 + 50% unstructured q (quantize first: three launches)", 5120, 5120, "bf16", 4, dict(w_sparsity=True, sparsity_mode='unstructured', first='q')),
     ("cfg5 ViT-L fc1 [4096,1024] f32 HBFP8 b16 1:4", 4096, 1024, "f32", 8, dict(mant_bits=7, block_size=16, N=1, M=4, w_sparsity=True)),
     ("cfg5 ViT-L act [8x197,1024] f32 HBFP8 b16 dense (identifier in)", 8 * 197, 1024, "f32", 8, dict(mant_bits=7, block_size=16, N=1, M=4, w_sparsity=True, _ident='in')),
     ("down_proj bf16 HBFP4 b64 4:8 s (N:8 in the flat kernel)", 4096, 11008, "bf16", 4, dict(w_sparsity=True, N=4, M=8)),
