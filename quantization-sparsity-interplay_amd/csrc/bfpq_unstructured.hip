@@ -19,6 +19,13 @@ namespace {
 //   fuse != 0 (single device, 16-bit dtypes): only the 256 coarse sums go to the global histogram; the workgroup publishes
 //     its window, draws a ticket, and the last one resolves the selection (bfpq_select.h) -- one launch.
 //   fuse == 0: the non-zero fine bins are flushed by integer atomics (deterministic) for the resolve launch.
+// Where bin b of the 15-bit histogram lives in the LDS: the low five bits (the bank) are mixed with bits 5-14.  A tensor that went
+// through the quantizer before it is pruned (first = 'q', or a checkpoint stored in HBFP values) has only a few distinct magnitudes and
+// their low mantissa bits are all zero: unmixed, EVERY LDS atomic of a wave landed in bank 0 and the launch took 58 us on [5120,5120] bf16
+// instead of 20.  The map is a bijection that keeps each aligned group of 32 bins (hence each coarse bin of 128) in place, so sums over
+// coarse bins do not see it; whoever reads a fine bin asks through it.
+__device__ __forceinline__ uint32_t swz15(uint32_t b) { return b ^ (((b >> 5) ^ (b >> 10)) & 31u); }
+
 template <int DT, bool FAST>
 __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int64_t numel, int pass, int shift, int nbits, int first, int last,
                                                              SelWs* ws, uint32_t* hist_ext, int64_t k, int64_t numel_global, int fuse)
@@ -57,7 +64,8 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t k2 = pk_min_i16_s(d[j] & absm, nanc);
-                const uint32_t ka = k2 & 0xffffu, kb = k2 >> 16;
+                const uint32_t s2 = k2 ^ (((k2 >> 5) ^ (k2 >> 10)) & 0x001f001fu);     // swz15 of both halves at once (what crosses the halves is masked away)
+                const uint32_t ka = s2 & 0xffffu, kb = s2 >> 16;                       // (swz15(k) == 0 only for k == 0)
                 if (ka) atomicAdd(&s_hist[ka], 1u); else zeros++;
                 if (kb) atomicAdd(&s_hist[kb], 1u); else zeros++;
             }
@@ -74,7 +82,10 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
             for (int j = 0; j < VEC; j++) {
                 const uint32_t key = mag_key<DT>(cur[j]);
                 const bool real = FAST || item * VEC + j < numel;
-                if (real && (key & pmask) == pval) atomicAdd(&s_hist[(key >> shift) & dmask], 1u);
+                if (real && (key & pmask) == pval) {
+                    const uint32_t bin = (key >> shift) & dmask;
+                    atomicAdd(&s_hist[nbits == 15 ? swz15(bin) : bin], 1u);
+                }
             }
 #pragma unroll
             for (int j = 0; j < VEC; j++) cur[j] = nxt[j];
@@ -87,7 +98,7 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
         coarse_from_lds<kCoarseBins, false>(s_hist, s_coarse);
         __syncthreads();
         const double frac = numel_global > 0 ? (double)k / (double)numel_global : 0.0;
-        if (!seg_publish_and_ticket<kCoarseBins>(s_coarse, s_res, ws, frac, [&](uint32_t b) { return s_hist[b]; })) return;
+        if (!seg_publish_and_ticket<kCoarseBins>(s_coarse, s_res, ws, frac, [&](uint32_t b) { return s_hist[swz15(b)]; })) return;
         STAMP(0, 6);
         fused_resolve<DT, FAST, kCoarseBins>(in, numel, n_items, g, ws, s_hist, (uint32_t)k, k, shift, 0u, 0u, last != 0);
         STAMP(0, 7);
@@ -146,7 +157,7 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
         for (int cb = t >> 6; cb < kCoarseBins; cb += kSelThreads / 64) {
             if (s_coarse[cb] == 0) continue;                   // (wave-uniform)
             const int i = cb * 128 + lane;
-            const uint32_t c0 = s_hist[i], c1 = s_hist[i + 64];
+            const uint32_t c0 = s_hist[swz15((uint32_t)i)], c1 = s_hist[swz15((uint32_t)i + 64u)];
             if (c0) atomicAdd(&hist[i], c0);
             if (c1) atomicAdd(&hist[i + 64], c1);
         }
@@ -165,8 +176,8 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
     }
     __syncthreads();
     const int lo = (int)s_res[0];
-    pub_store(&ws->windows[blockIdx.x][t], s_hist[lo + t]);
-    pub_store(&ws->windows[blockIdx.x][kSelThreads + t], s_hist[lo + kSelThreads + t]);
+    pub_store(&ws->windows[blockIdx.x][t], s_hist[swz15((uint32_t)(lo + t))]);
+    pub_store(&ws->windows[blockIdx.x][kSelThreads + t], s_hist[swz15((uint32_t)(lo + kSelThreads + t))]);
     STAMP(0, 5);
 }
 

@@ -1151,6 +1151,25 @@ def test_unstructured_on_already_sparse_tensors(dname):
     assert e0.elapsed_time(e1) / 10 < 1.0, f"{e0.elapsed_time(e1) / 10:.3f} ms per call: the serial recount path is back"
 
 
+@pytest.mark.parametrize("dname", ["bf16", "f16", "f32"])
+def test_unstructured_on_already_quantized_tensors(dname):
+    """A tensor that went through the quantizer BEFORE it is pruned (first = 'q', or a checkpoint stored in HBFP values): a hundred-odd distinct
+    magnitudes whose low mantissa bits are all zero.  The selection's LDS histogram maps its bins through a bank swizzle for this case (unmixed,
+    every atomic of a wave fell into bank 0); windows, flush and recount read through the same map.  Bit for bit against the engine's tie rule
+    on the host, for HBFP4 and HBFP8 values, and the composed q-first call against the oracle's contract."""
+    dt = DT[dname]
+    xc = synth(1536, 4096, dt, 0.02, seed=21)
+    for m in (3, 7):
+        q = O.no_sparsity_float_to_bfp(xc, 64, m)
+        for frac in (0.5, 0.25):
+            got = bfp_ops._unstructured_sparsity(q.to(DEV), 'cuda', frac)
+            assert_bits_equal(bits(got), bits(_flat_order_prune(q, frac)), dt, f"already HBFP{m + 1} {dname} frac={frac}")
+        c = cfg(w_sparsity=True, sparsity_mode='unstructured', first='q', mant_bits=m)
+        yq = bfp_ops.float_to_bfp_blocked(xc.to(DEV), **c, identifier='w')
+        _tie_class_check(q, yq, 0.5, dt, f"q-first unstructured HBFP{m + 1} {dname}")
+        assert int((yq == 0).sum()) >= xc.numel() // 2
+
+
 @pytest.mark.parametrize("shape", [(13824, 5120), (5120, 13824)])
 def test_oracle_parity_cfg4_13b_mlp_shapes(shape):
     """cfg 4 at the LLaMA-13B MLP shapes (gate/up [13824,5120], down [5120,13824]) bf16, HBFP4 + 50 % unstructured,
