@@ -39,14 +39,31 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
     const int t = threadIdx.x;
     const int nbins = 1 << nbits;
     STAMP(0, 0);
-    for (int i = t; i < nbins / 4; i += kSelThreads) reinterpret_cast<uint4*>(s_hist)[i] = make_uint4(0, 0, 0, 0);
-    if (t < kCoarseBins) s_coarse[t] = 0;
-    __syncthreads();
-    const uint32_t pmask = first ? 0u : ws->st.prefix_mask, pval = first ? 0u : ws->st.prefix;   // pass 0 reads no state
-    const uint32_t dmask = (uint32_t)nbins - 1u;
     const int64_t n_items = (numel + VEC - 1) / VEC;
     const SegGeom g = seg_geom(n_items);
     const int64_t i0 = (int64_t)blockIdx.x * g.L, i1 = i0 + g.L < n_items ? i0 + g.L : n_items;
+    // 16-bit dtypes: the thread's first item is asked for before the LDS is cleared, and the barrier behind the clearing doubles as the
+    // vote on how the segment is counted (below): no barrier of its own
+    [[maybe_unused]] uint4 v_first = make_uint4(0, 0, 0, 0);
+    bool low_first = false;
+    if constexpr (FAST && VEC == 8) {
+        const int64_t item0 = i0 + t, lastv = n_items - 1;
+        v_first = reinterpret_cast<const uint4*>(in)[item0 < lastv ? item0 : lastv];
+    }
+    for (int i = t; i < nbins / 4; i += kSelThreads) reinterpret_cast<uint4*>(s_hist)[i] = make_uint4(0, 0, 0, 0);
+    if (t < kCoarseBins) s_coarse[t] = 0;
+    if constexpr (FAST && VEC == 8) low_first = i0 + t < i1 && ((v_first.x | v_first.y | v_first.z | v_first.w) & 0x001f001fu) != 0u;
+    bool rep = __syncthreads_or((int)low_first) == 0 && FAST && VEC == 8;      // (block-uniform) the segment is counted into replicas, see below
+    const uint32_t pmask = first ? 0u : ws->st.prefix_mask, pval = first ? 0u : ws->st.prefix;   // pass 0 reads no state
+    const uint32_t dmask = (uint32_t)nbins - 1u;
+    auto fine_at = [&](uint32_t b) __attribute__((always_inline)) -> uint32_t {      // the count of fine bin b of the 15-bit digit
+        if (!rep) return s_hist[swz15(b)];
+        if (b & 31u) return 0u;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const uint4 c4 = *reinterpret_cast<const uint4*>(&s_hist[b + 4 * q]); sum += c4.x + c4.y + c4.z + c4.w; }
+        return sum;
+    };
     if constexpr (FAST && VEC == 8) {
         // 16-bit dtypes: one pass over the whole 15-bit key (shift 0, no prefix to match): two keys per packed and/min,
         // unconditional LDS atomics; one-ahead prefetch with a clamped, unconditional load
@@ -54,24 +71,45 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
         // Zeros are counted in a register and added once: a tensor that is already sparse sends half of a wave's atomics to ONE
         // LDS word otherwise (52 % zeros: the launch took twice as long).
         const int64_t lastv = n_items - 1;
-        int64_t item = i0 + t;
-        uint32_t zeros = 0;
-        uint4 v = reinterpret_cast<const uint4*>(in)[item < lastv ? item : lastv];
-        for (; item < i1; item += kSelThreads) {
-            const int64_t pf = item + kSelThreads;
-            const uint4 nv = reinterpret_cast<const uint4*>(in)[pf < lastv ? pf : lastv];
-            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+        // COARSE-KEYED tensors (r03): when the low five bits of every key of the segment are zero -- HBFP values of up to three mantissa bits
+        // in bf16, the quantizer's output under first = 'q' or a stored checkpoint -- 31 of every 32 bins stay empty while a wave's 64 atomics fall
+        // on a dozen words.  Such a segment is counted into REPLICAS: lane l adds to word swz15(key) ^ (l & 31) of the key's own aligned group
+        // of 32, so equal keys of a wave meet in different words and banks; a bin's count is the sum of its group (fine_at below), the coarse
+        // sums see no difference.  The first item of every thread decides (the vote rides on the barrier behind the LDS clearing); a key with low bits met later raises `viol` and the
+        // segment is counted again the plain way (a mixed tensor pays twice, the result is the same).
+        auto count_pass = [&](auto rep_tag, uint4 v) __attribute__((always_inline)) {      // v: the thread's first item (loaded by the caller)
+            constexpr bool REP = decltype(rep_tag)::value;
+            const uint32_t l5 = REP ? (uint32_t)(t & 31) : 0u;
+            int64_t item = i0 + t;
+            uint32_t zeros = 0, low = 0;
+            for (; item < i1; item += kSelThreads) {
+                const int64_t pf = item + kSelThreads;
+                const uint4 nv = reinterpret_cast<const uint4*>(in)[pf < lastv ? pf : lastv];
+                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t k2 = pk_min_i16_s(d[j] & absm, nanc);
-                const uint32_t s2 = k2 ^ (((k2 >> 5) ^ (k2 >> 10)) & 0x001f001fu);     // swz15 of both halves at once (what crosses the halves is masked away)
-                const uint32_t ka = s2 & 0xffffu, kb = s2 >> 16;                       // (swz15(k) == 0 only for k == 0)
-                if (ka) atomicAdd(&s_hist[ka], 1u); else zeros++;
-                if (kb) atomicAdd(&s_hist[kb], 1u); else zeros++;
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t k2 = pk_min_i16_s(d[j] & absm, nanc);
+                    if constexpr (REP) low |= k2;
+                    const uint32_t s2 = k2 ^ (((k2 >> 5) ^ (k2 >> 10)) & 0x001f001fu);     // swz15 of both halves at once (what crosses the halves is masked away)
+                    const uint32_t ka = s2 & 0xffffu, kb = s2 >> 16;                       // (swz15(k) == 0 only for k == 0)
+                    if (ka) atomicAdd(&s_hist[ka ^ l5], 1u); else zeros++;
+                    if (kb) atomicAdd(&s_hist[kb ^ l5], 1u); else zeros++;
+                }
+                v = nv;
             }
-            v = nv;
-        }
-        if (zeros) atomicAdd(&s_hist[0], zeros);
+            if (zeros) atomicAdd(&s_hist[0], zeros);
+            return (low & 0x001f001fu) != 0u;
+        };
+        const uint4 v0 = v_first;
+        if (rep) {
+            const bool viol = count_pass(std::true_type{}, v0);
+            if (__syncthreads_or((int)viol)) {                                             // (block-uniform) not coarse-keyed after all: again, the plain way
+                rep = false;
+                for (int i = t; i < nbins / 4; i += kSelThreads) reinterpret_cast<uint4*>(s_hist)[i] = make_uint4(0, 0, 0, 0);
+                __syncthreads();
+                count_pass(std::false_type{}, v0);
+            }
+        } else count_pass(std::false_type{}, v0);
     } else {
         int64_t item = i0 + t;
         uint32_t cur[VEC], nxt[VEC];
@@ -98,7 +136,7 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
         coarse_from_lds<kCoarseBins, false>(s_hist, s_coarse);
         __syncthreads();
         const double frac = numel_global > 0 ? (double)k / (double)numel_global : 0.0;
-        if (!seg_publish_and_ticket<kCoarseBins>(s_coarse, s_res, ws, frac, [&](uint32_t b) { return s_hist[swz15(b)]; })) return;
+        if (!seg_publish_and_ticket<kCoarseBins>(s_coarse, s_res, ws, frac, [&](uint32_t b) { return fine_at(b); })) return;
         STAMP(0, 6);
         fused_resolve<DT, FAST, kCoarseBins>(in, numel, n_items, g, ws, s_hist, (uint32_t)k, k, shift, 0u, 0u, last != 0);
         STAMP(0, 7);
@@ -157,7 +195,7 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
         for (int cb = t >> 6; cb < kCoarseBins; cb += kSelThreads / 64) {
             if (s_coarse[cb] == 0) continue;                   // (wave-uniform)
             const int i = cb * 128 + lane;
-            const uint32_t c0 = s_hist[swz15((uint32_t)i)], c1 = s_hist[swz15((uint32_t)i + 64u)];
+            const uint32_t c0 = fine_at((uint32_t)i), c1 = fine_at((uint32_t)i + 64u);
             if (c0) atomicAdd(&hist[i], c0);
             if (c1) atomicAdd(&hist[i + 64], c1);
         }
@@ -176,8 +214,8 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
     }
     __syncthreads();
     const int lo = (int)s_res[0];
-    pub_store(&ws->windows[blockIdx.x][t], s_hist[swz15((uint32_t)(lo + t))]);
-    pub_store(&ws->windows[blockIdx.x][kSelThreads + t], s_hist[swz15((uint32_t)(lo + kSelThreads + t))]);
+    pub_store(&ws->windows[blockIdx.x][t], fine_at((uint32_t)(lo + t)));
+    pub_store(&ws->windows[blockIdx.x][kSelThreads + t], fine_at((uint32_t)(lo + kSelThreads + t)));
     STAMP(0, 5);
 }
 

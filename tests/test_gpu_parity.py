@@ -1154,8 +1154,9 @@ def test_unstructured_on_already_sparse_tensors(dname):
 @pytest.mark.parametrize("dname", ["bf16", "f16", "f32"])
 def test_unstructured_on_already_quantized_tensors(dname):
     """A tensor that went through the quantizer BEFORE it is pruned (first = 'q', or a checkpoint stored in HBFP values): a hundred-odd distinct
-    magnitudes whose low mantissa bits are all zero.  The selection's LDS histogram maps its bins through a bank swizzle for this case (unmixed,
-    every atomic of a wave fell into bank 0); windows, flush and recount read through the same map.  Bit for bit against the engine's tie rule
+    magnitudes whose low mantissa bits are all zero.  The selection's LDS histogram maps its bins through a bank swizzle (unmixed, every atomic
+    of a wave fell into bank 0) and counts a segment whose keys all have five zero low bits into 32 replicas per bin; windows, flush and recount
+    read through the same map.  Bit for bit against the engine's tie rule
     on the host, for HBFP4 and HBFP8 values, and the composed q-first call against the oracle's contract."""
     dt = DT[dname]
     xc = synth(1536, 4096, dt, 0.02, seed=21)
@@ -1164,6 +1165,14 @@ def test_unstructured_on_already_quantized_tensors(dname):
         for frac in (0.5, 0.25):
             got = bfp_ops._unstructured_sparsity(q.to(DEV), 'cuda', frac)
             assert_bits_equal(bits(got), bits(_flat_order_prune(q, frac)), dt, f"already HBFP{m + 1} {dname} frac={frac}")
+        if m == 3:
+            # coarse-keyed at the start of every segment, a few full-precision elements further in: the segments that meet one are counted
+            # into replicas first and again the plain way; segments without one keep their replicas -- the two kinds publish the same counts
+            mixed = q.clone().view(-1)
+            mixed[700001::900001] = xc.view(-1)[700001::900001] * 1.37
+            mixed = mixed.view(q.shape)
+            got = bfp_ops._unstructured_sparsity(mixed.to(DEV), 'cuda', 0.5)
+            assert_bits_equal(bits(got), bits(_flat_order_prune(mixed, 0.5)), dt, f"HBFP4 with stray full-precision elements {dname}")
         c = cfg(w_sparsity=True, sparsity_mode='unstructured', first='q', mant_bits=m)
         yq = bfp_ops.float_to_bfp_blocked(xc.to(DEV), **c, identifier='w')
         _tie_class_check(q, yq, 0.5, dt, f"q-first unstructured HBFP{m + 1} {dname}")
