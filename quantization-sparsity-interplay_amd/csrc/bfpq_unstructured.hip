@@ -45,15 +45,22 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
     // 16-bit dtypes: the thread's first item is asked for before the LDS is cleared, and the barrier behind the clearing doubles as the
     // vote on how the segment is counted (below): no barrier of its own
     [[maybe_unused]] uint4 v_first = make_uint4(0, 0, 0, 0);
-    bool low_first = false;
-    if constexpr (FAST && VEC == 8) {
+    [[maybe_unused]] uint32_t g_first[VEC];
+    constexpr bool kFast16 = FAST && VEC == 8;
+    const bool may_rep = kFast16 || (nbits == 15 && first != 0);               // the first 15-bit digit of any dtype
+    if constexpr (kFast16) {
         const int64_t item0 = i0 + t, lastv = n_items - 1;
         v_first = reinterpret_cast<const uint4*>(in)[item0 < lastv ? item0 : lastv];
-    }
+    } else sweep_load<DT, FAST>(in, i0 + t, n_items, numel, g_first);
     for (int i = t; i < nbins / 4; i += kSelThreads) reinterpret_cast<uint4*>(s_hist)[i] = make_uint4(0, 0, 0, 0);
     if (t < kCoarseBins) s_coarse[t] = 0;
-    if constexpr (FAST && VEC == 8) low_first = i0 + t < i1 && ((v_first.x | v_first.y | v_first.z | v_first.w) & 0x001f001fu) != 0u;
-    bool rep = __syncthreads_or((int)low_first) == 0 && FAST && VEC == 8;      // (block-uniform) the segment is counted into replicas, see below
+    bool low_first = !may_rep;
+    if constexpr (kFast16) low_first = i0 + t < i1 && ((v_first.x | v_first.y | v_first.z | v_first.w) & 0x001f001fu) != 0u;
+    else if (may_rep && i0 + t < i1) {
+#pragma unroll
+        for (int j = 0; j < VEC; j++) low_first |= (FAST || (i0 + t) * VEC + j < numel) && ((mag_key<DT>(g_first[j]) >> shift) & 31u) != 0u;
+    }
+    bool rep = __syncthreads_or((int)low_first) == 0;      // (block-uniform) the segment is counted into replicas, see below
     const uint32_t pmask = first ? 0u : ws->st.prefix_mask, pval = first ? 0u : ws->st.prefix;   // pass 0 reads no state
     const uint32_t dmask = (uint32_t)nbins - 1u;
     auto fine_at = [&](uint32_t b) __attribute__((always_inline)) -> uint32_t {      // the count of fine bin b of the 15-bit digit
@@ -111,23 +118,42 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
             }
         } else count_pass(std::false_type{}, v0);
     } else {
-        int64_t item = i0 + t;
-        uint32_t cur[VEC], nxt[VEC];
-        sweep_load<DT, FAST>(in, item, n_items, numel, cur);
-        for (; item < i1; item += kSelThreads) {
-            sweep_load<DT, FAST>(in, item + kSelThreads, n_items, numel, nxt);
+        // (fp32, ragged shapes, later digits) the same two passes for the first 15-bit digit: fp32 tensors that hold HBFP or bf16 values have
+        // five zero low bits in it as well
+        auto count_generic = [&](auto rep_tag) __attribute__((always_inline)) {
+            constexpr bool REP = decltype(rep_tag)::value;
+            const uint32_t l5 = REP ? (uint32_t)(t & 31) : 0u;
+            uint32_t low = 0;
+            int64_t item = i0 + t;
+            uint32_t cur[VEC], nxt[VEC];
 #pragma unroll
-            for (int j = 0; j < VEC; j++) {
-                const uint32_t key = mag_key<DT>(cur[j]);
-                const bool real = FAST || item * VEC + j < numel;
-                if (real && (key & pmask) == pval) {
-                    const uint32_t bin = (key >> shift) & dmask;
-                    atomicAdd(&s_hist[nbits == 15 ? swz15(bin) : bin], 1u);
+            for (int j = 0; j < VEC; j++) cur[j] = g_first[j];
+            for (; item < i1; item += kSelThreads) {
+                sweep_load<DT, FAST>(in, item + kSelThreads, n_items, numel, nxt);
+#pragma unroll
+                for (int j = 0; j < VEC; j++) {
+                    const uint32_t key = mag_key<DT>(cur[j]);
+                    const bool real = FAST || item * VEC + j < numel;
+                    if (real && (key & pmask) == pval) {
+                        const uint32_t bin = (key >> shift) & dmask;
+                        if constexpr (REP) low |= bin;
+                        atomicAdd(&s_hist[nbits == 15 ? swz15(bin) ^ l5 : bin], 1u);
+                    }
                 }
-            }
 #pragma unroll
-            for (int j = 0; j < VEC; j++) cur[j] = nxt[j];
-        }
+                for (int j = 0; j < VEC; j++) cur[j] = nxt[j];
+            }
+            return (low & 31u) != 0u;
+        };
+        if (rep) {
+            const bool viol = count_generic(std::true_type{});
+            if (__syncthreads_or((int)viol)) {
+                rep = false;
+                for (int i = t; i < nbins / 4; i += kSelThreads) reinterpret_cast<uint4*>(s_hist)[i] = make_uint4(0, 0, 0, 0);
+                __syncthreads();
+                count_generic(std::false_type{});
+            }
+        } else count_generic(std::false_type{});
     }
     STAMP(0, 1);
     __syncthreads();
