@@ -290,6 +290,16 @@ def main():
                                           "launch": "hipGraph", "rotating_buffers": R,
                                           "what": f"[5120,5120] {args.dtype}: global 50 % magnitude pruning then HBFP4 block 64 (first='s'), selection launch + fused "
                                                   "prune+quantize launch; two-read figure = 6 B/element (the tensor is read by both launches), single-read = 4 B/element"}
+            # ... and the other order (first='q': quantize, then prune the quantized tensor), through the reference-shaped call
+            c4q = dict(c4, first='q')
+
+            def unstructured_q_step(i):
+                return bfp_ops.float_to_bfp_blocked(u_ins[i % R], **c4q, identifier='w')
+            _, uq_ms = timed_loop(unstructured_q_step, short, 10, True, repeats=5)
+            uq_us = uq_ms * 1e3 / short
+            extra["cfg4_unstructured_q_first"] = {"us": uq_us, "elems/s": un / uq_us * 1e6, "launch": "hipGraph", "rotating_buffers": R,
+                                                  "what": f"[5120,5120] {args.dtype}: HBFP4 block 64 then global 50 % magnitude pruning of the QUANTIZED tensor (first='q'): quantize launch, "
+                                                          "selection launch on its output, prune launch (10 B/element); float_to_bfp_blocked returns a new tensor per call"}
             del u_ins, u_outs
             # (3) the same launches spread over two lanes (the caller's stream and one side stream: bfpq_fake_quantize_list): what a pass
             #     over many tensors gets per tensor, the tail of one launch running beside the ramp of the next
