@@ -240,3 +240,26 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.lower().replace("# oracle", ""), os.path.join(dirpath, f)
+
+
+def test_selection_histogram_swizzle_invariants():
+    """what k_select_hist relies on (csrc/bfpq_unstructured.hip, swz15): the LDS index map of the 15-bit histogram is a bijection that keeps every
+    aligned group of 32 bins in place (so sums over coarse bins of 128 do not see it), maps 0 to 0 only (the zero test runs on the swizzled key),
+    the packed form mixes both 16-bit halves of a dword exactly like the scalar one, and a coarse-keyed bin's 32 replica words
+    swz15(b) ^ lane are exactly its own group"""
+    import numpy as np
+    b = np.arange(1 << 15, dtype=np.uint32)
+    swz = lambda x: x ^ (((x >> 5) ^ (x >> 10)) & 31)
+    s = swz(b)
+    assert np.array_equal(np.sort(s), b)                                   # bijection
+    assert np.array_equal(s >> 5, b >> 5)                                  # every aligned group of 32 stays in place
+    assert int((s == 0).sum()) == 1 and s[0] == 0
+    rng = np.random.default_rng(5)
+    lo, hi = rng.integers(0, 1 << 15, 100000, dtype=np.uint32), rng.integers(0, 1 << 15, 100000, dtype=np.uint32)
+    k2 = lo | (hi << 16)
+    s2 = k2 ^ (((k2 >> 5) ^ (k2 >> 10)) & 0x001F001F)
+    assert np.array_equal(s2 & 0xFFFF, swz(lo)) and np.array_equal(s2 >> 16, swz(hi))
+    coarse = b[(b & 31) == 0]
+    for lane in range(64):
+        assert np.array_equal((swz(coarse) ^ (lane & 31)) >> 5, coarse >> 5)
+    assert all(len({int(swz(c) ^ (lane & 31)) for lane in range(32)}) == 32 for c in coarse[:64])
