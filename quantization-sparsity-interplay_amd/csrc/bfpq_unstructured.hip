@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
         auto count_generic = [&](auto rep_tag) __attribute__((always_inline)) {
             constexpr bool REP = decltype(rep_tag)::value;
             const uint32_t l5 = REP ? (uint32_t)(t & 31) : 0u;
-            uint32_t low = 0;
+            uint32_t low = 0, zero_bin = 0;
             int64_t item = i0 + t;
             uint32_t cur[VEC], nxt[VEC];
 #pragma unroll
@@ -137,12 +137,14 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist(const void* in, int
                     if (real && (key & pmask) == pval) {
                         const uint32_t bin = (key >> shift) & dmask;
                         if constexpr (REP) low |= bin;
-                        atomicAdd(&s_hist[nbits == 15 ? swz15(bin) ^ l5 : bin], 1u);
+                        if (bin) atomicAdd(&s_hist[nbits == 15 ? swz15(bin) ^ l5 : bin], 1u);
+                        else zero_bin++;                       // (as in the 16-bit loop: an already-sparse tensor sends half of a wave's atomics to ONE word otherwise)
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < VEC; j++) cur[j] = nxt[j];
             }
+            if (zero_bin) atomicAdd(&s_hist[0], zero_bin);
             return (low & 31u) != 0u;
         };
         if (rep) {
@@ -271,7 +273,7 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist_lo16(const void* in
     const int64_t n_items = (numel + VEC - 1) / VEC;
     const SegGeom g = seg_geom(n_items);
     const int64_t i0 = (int64_t)blockIdx.x * g.L, i1 = i0 + g.L < n_items ? i0 + g.L : n_items;
-    uint32_t matched = 0;
+    uint32_t matched = 0, zero_low = 0;
     {
         int64_t item = i0 + t;
         uint32_t cur[VEC], nxt[VEC];
@@ -282,13 +284,15 @@ __global__ void __launch_bounds__(kSelThreads) k_select_hist_lo16(const void* in
             for (int j = 0; j < VEC; j++) {
                 const uint32_t key = mag_key<DT>(cur[j]);
                 if ((FAST || item * VEC + j < numel) && (key & pmask) == pval) {
-                    atomicAdd(&s_hist[(key & 0xffffu) >> 1], (key & 1u) ? 0x10000u : 1u);
+                    if (key & 0xffffu) atomicAdd(&s_hist[(key & 0xffffu) >> 1], (key & 1u) ? 0x10000u : 1u);
+                    else zero_low++;                           // zeros of an already-sparse tensor, bf16 / HBFP values held in fp32: one word otherwise
                     matched++;
                 }
             }
 #pragma unroll
             for (int j = 0; j < VEC; j++) cur[j] = nxt[j];
         }
+        if (zero_low) atomicAdd(&s_hist[0], zero_low);         // (a count beyond 16 bits carries into the neighbour half: the proof below fails and the segment is recounted, as before)
     }
     __syncthreads();
     coarse_from_lds<NCB, true>(s_hist, s_coarse);
